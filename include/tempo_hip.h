@@ -1,0 +1,305 @@
+/*
+ * tempo_hip.h -- C ABI of libtempo_hip.so, the MI355X (gfx950) engine behind tempo's TSDF
+ * hot path.
+ *
+ * The reference (souvik-databricks/tempo) has no FFI or plugin interface: its TSDF methods
+ * build Spark logical plans and Spark executes them.  Each entry point below therefore
+ * replaces the Spark physical operators that one TSDF method's plan expands to; the comment
+ * on every function cites the reference lines whose plan it stands in for.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer (HBM) unless the comment says "host";
+ *  - columns are contiguous 1-D arrays; a partition key is a dictionary id in [0, n_keys);
+ *    timestamps are int64 microseconds since the epoch (Spark TimestampType) unless
+ *    ts_is_seconds != 0 (an integral ts column);
+ *  - SQL NULL is a separate byte mask per column, 1 = valid; a NULL mask pointer = no NULLs;
+ *  - the caller owns and allocates inputs, outputs and the workspace
+ *    (tmp_*_workspace_bytes); the library allocates nothing and keeps no pointer;
+ *  - work is enqueued on `stream` (a hipStream_t); the call returns after enqueueing, except
+ *    for one small device->host read of key ranges that the ordering step needs;
+ *  - return value: TMP_OK or a negative TMP_E* code, message via tmp_last_error().
+ *  - row counts per call are limited to 2^31-1 (row indices are int32).
+ */
+#ifndef TEMPO_HIP_H
+#define TEMPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMP_ABI_VERSION 1
+
+#define TMP_OK 0
+#define TMP_EINVAL (-1)       /* bad argument */
+#define TMP_EWORKSPACE (-2)   /* workspace too small */
+#define TMP_EHIP (-3)         /* HIP runtime error */
+#define TMP_EUNSUPPORTED (-4) /* valid request outside what this build supports */
+
+int tmp_abi_version(void);
+/* Thread-local text of the last error on the calling thread ("" if none). */
+const char *tmp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Ordering: partitionBy(partitionCols).orderBy(...) + SortExec.
+ *
+ * Replaces the Exchange + Sort that every hot-path plan starts with:
+ *   python/tempo/tsdf.py:117-121  (asofJoin: order by combined_ts[, seq], rec_ind)
+ *   python/tempo/tsdf.py:563-572  (__baseWindow: order by ts.cast("long")[, seq.cast("long")])
+ *   python/tempo/resample.py:63   (groupBy(partitionCols, window(ts)))
+ * Output: out_perm[p] = input row at sorted position p (stable: ties keep input order).
+ * ts_unit: 0 = order by the exact ts value, 1 = ts is microseconds and the order key is
+ * floor(ts / 1e6) (timestamp.cast("long")).  seq may be NULL; seq NULLs sort first.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key; /* NULL: a single series */
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t ts_unit;
+  const int64_t *seq;
+  const uint8_t *seq_valid;
+  int32_t *out_perm;
+} tmp_sort_args;
+
+size_t tmp_sort_order_workspace_bytes(const tmp_sort_args *a);
+int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * AS-OF join match.
+ *
+ * Replaces the union + Window(last(col, ignorenulls) over rows unboundedPreceding..current)
+ * plan of TSDF.asofJoin / __getLastRightRow / __getTimePartitions:
+ *   python/tempo/tsdf.py:463-560, :111-162, :164-190.
+ * For every left row it returns which right row each joined column comes from:
+ *   out_row_idx[i]          last right row visible to left row i (skipNulls=False value rule,
+ *                           and the rule for columns without NULLs), or -1
+ *   out_mask_idx[m*n_left+i] last visible right row whose mask m is valid (skipNulls=True rule
+ *                           for a column with NULLs), or -1
+ *   out_missing[0]          1 if some left row has no visible right row
+ *   out_missing[1+m]        1 if some left row has no visible right row with mask m valid
+ *                           (the non_null_ct == 0 warning test, tsdf.py:142-158)
+ * "Visible" = same key and ordered before the left row by (ts, seq NULLS FIRST, right before
+ * left) -- tsdf.py:117-121; with skew != 0 additionally inside the left row's time bracket or
+ * carried over from the previous bracket, evaluated with the same fp64 expressions as
+ * tsdf.py:178-185 (ts_partition_val = tsPartitionVal, v_is_int = it was a Python int,
+ * one_minus_fraction = 1 - fraction computed by the caller in double).
+ * masks: HOST array of n_masks device pointers (<= TMP_MAX_MASKS).
+ */
+#define TMP_MAX_MASKS 16
+
+typedef struct {
+  int64_t n_left;
+  int64_t n_right;
+  const int32_t *key_left; /* NULL on both sides: a single series */
+  const int64_t *ts_left;
+  const int32_t *key_right;
+  const int64_t *ts_right;
+  const int64_t *seq_right;       /* NULL: right side has no sequence column */
+  const uint8_t *seq_right_valid; /* NULL: no NULLs */
+  int32_t n_keys;
+  int32_t ts_is_seconds;
+  int32_t n_masks;
+  const uint8_t *const *masks;
+  int32_t skew;
+  int32_t v_is_int;
+  double ts_partition_val;
+  double one_minus_fraction;
+  int32_t *out_row_idx;  /* [n_left] */
+  int32_t *out_mask_idx; /* [n_masks][n_left] */
+  int32_t *out_missing;  /* [1 + n_masks] */
+} tmp_asof_args;
+
+size_t tmp_asof_join_workspace_bytes(const tmp_asof_args *a);
+int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row gather: out[i] = idx[i] >= 0 ? src[idx[i]] : 0 ; out_valid[i] = idx[i] >= 0 &&
+ * (src_valid == NULL || src_valid[idx[i]]).  elem_bytes in {1, 4, 8}.
+ * Replaces the Project that materialises the joined right columns (tsdf.py:139,147) and the
+ * row reordering implied by window operators.
+ */
+int tmp_gather(const void *src, const uint8_t *src_valid, int32_t elem_bytes, const int32_t *idx,
+               int64_t n, void *out, uint8_t *out_valid, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * withRangeStats: rolling RANGE-frame statistics.
+ *
+ * Replaces WindowExec over rangeBetween(-rangeBackWindowSecs, 0) with mean/count/min/max/
+ * sum/stddev and the derived zscore: python/tempo/tsdf.py:673-721 (frame :704, aggregates
+ * :710-717), ordering :563-572.  Frame of a row = rows of the same key whose
+ * floor-second lies in [sec - range_back_secs, sec] (later same-second rows included).
+ * Outputs are in sorted (key, sec) order; out_perm[p] = input row at output position p.
+ * x_is_i64 = 0: x, out_min, out_max, out_sum are double arrays;
+ * x_is_i64 = 1: they are int64 arrays (Spark sums int/bigint in int64, min/max stay integral).
+ * out_valid[p]: bit0 = mean/min/max/sum not NULL (count > 0), bit1 = stddev not NULL
+ * (count > 1), bit2 = zscore not NULL.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t ts_is_seconds;
+  int32_t x_is_i64;
+  const void *x;
+  const uint8_t *x_valid;
+  int64_t range_back_secs;
+  int32_t *out_perm;
+  double *out_mean;
+  int64_t *out_count;
+  void *out_min;
+  void *out_max;
+  void *out_sum;
+  double *out_stddev;
+  double *out_zscore;
+  uint8_t *out_valid;
+} tmp_range_stats_args;
+
+size_t tmp_range_stats_workspace_bytes(const tmp_range_stats_args *a);
+int tmp_range_stats(const tmp_range_stats_args *a, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * EMA: fixed-tap FIR over the previous rows of the same series.
+ *
+ * Replaces the `window` Lag frames + running sum of python/tempo/tsdf.py:615-635:
+ * out[p] = 0 + w[0]*x[p] + w[1]*x[p-1] + ... (left-to-right adds, NULL or missing taps add
+ * nothing), rows ordered as tsdf.py:563-572.  weights: HOST array of n_taps doubles computed
+ * by the caller as exp_factor * (1 - exp_factor) ** i (tsdf.py:629).  n_taps <= TMP_MAX_TAPS.
+ * Output in sorted order with out_perm as above.
+ */
+#define TMP_MAX_TAPS 1024
+
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t ts_is_seconds;
+  const int64_t *seq;
+  const uint8_t *seq_valid;
+  const double *x;
+  const uint8_t *x_valid;
+  int32_t n_taps;
+  const double *weights;
+  int32_t *out_perm;
+  double *out_ema;
+} tmp_ema_args;
+
+size_t tmp_ema_workspace_bytes(const tmp_ema_args *a);
+int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * withLookbackFeatures: trailing-window feature tensor.
+ *
+ * Replaces collect_list(array(featureCols)) over rowsBetween(-L, -1):
+ * python/tempo/tsdf.py:637-671.  For the row at sorted position p with m = min(L, rows before
+ * it in its series): out_feat[o][l][f] = x_f of the row at position p - m + l (oldest first).
+ * exact_size != 0 keeps only rows with m == L (tsdf.py:668-669): then o counts kept rows,
+ * out_rows[o] = input row of output row o, and *out_count (device int64) = number kept.
+ * exact_size == 0: o = p for every row, out_len[p] = m, entries l >= m are zero/invalid.
+ * x / x_valid: HOST arrays of n_feat device pointers.  out_feat_valid may be NULL when no
+ * feature column has NULLs.
+ */
+#define TMP_MAX_FEATURES 64
+
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t ts_is_seconds;
+  const int64_t *seq;
+  const uint8_t *seq_valid;
+  int32_t n_feat;
+  const double *const *x;
+  const uint8_t *const *x_valid;
+  int32_t lookback;
+  int32_t exact_size;
+  int32_t *out_rows;       /* [n] */
+  int32_t *out_len;        /* [n], exact_size == 0 only (may be NULL otherwise) */
+  double *out_feat;        /* [n][lookback][n_feat] capacity */
+  uint8_t *out_feat_valid; /* same shape, or NULL */
+  int64_t *out_count;      /* device scalar */
+} tmp_lookback_args;
+
+size_t tmp_lookback_workspace_bytes(const tmp_lookback_args *a);
+int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * resample: tumbling-bucket aggregation.
+ *
+ * Replaces window(ts, "<n> <unit>") + groupBy(partitionCols, agg_key).agg(...):
+ * python/tempo/resample.py:25-117 (bucket :33, floor :61-66, mean :67-72, min :73-79,
+ * max :80-86, ceil :87-92).  Bucket start = ts - ((ts mod dur_us) + dur_us) mod dur_us.
+ * Buckets come out ordered by (key, start); *out_count (device int64) = number of buckets.
+ * func: TMP_FUNC_*.  cols: HOST array of n_cols device pointers, col_is_i64[c] selects
+ * double or int64 (int64 also carries order-preserving codes of string columns).
+ *   mean          -> out_f64[c*n + b]
+ *   min / max     -> out_f64 or out_i64 [c*n + b] by column type
+ *   floor / ceil  -> out_row[b] = input row with the smallest / largest (ts, cols...) tuple
+ *                    under Spark struct ordering (NULL smallest, NaN greatest)
+ * out_valid[c*n + b] = result not NULL (mean/min/max).
+ */
+#define TMP_FUNC_FLOOR 0
+#define TMP_FUNC_MIN 1
+#define TMP_FUNC_MAX 2
+#define TMP_FUNC_MEAN 3
+#define TMP_FUNC_CEIL 4
+#define TMP_MAX_COLS 64
+
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int64_t dur_us;
+  int32_t func;
+  int32_t n_cols;
+  const void *const *cols;
+  const int32_t *col_is_i64; /* host */
+  const uint8_t *const *col_valid;
+  int32_t *out_key;   /* [n] capacity */
+  int64_t *out_start; /* [n] */
+  double *out_f64;    /* [n_cols][n] */
+  int64_t *out_i64;   /* [n_cols][n] */
+  uint8_t *out_valid; /* [n_cols][n] */
+  int32_t *out_row;   /* [n] */
+  int64_t *out_count; /* device scalar */
+} tmp_resample_args;
+
+size_t tmp_resample_workspace_bytes(const tmp_resample_args *a);
+int tmp_resample(const tmp_resample_args *a, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Key shuffle, device side: Exchange hashpartitioning(partitionCols).
+ *
+ * Replaces the shuffle that Window.partitionBy / groupBy imply (tsdf.py:121, :571,
+ * resample.py:63) on a multi-GPU node: rows are bucketed by owner = hash(key) % n_parts so
+ * that one all-to-all moves every series to the GPU that owns it.
+ * out_perm[p] = input row at position p of the bucketed order (stable within a bucket),
+ * out_counts[r] (device int64[n_parts]) = rows owned by part r.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_parts;
+  int32_t *out_perm;
+  int64_t *out_counts;
+} tmp_partition_args;
+
+size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a);
+int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t workspace_bytes,
+                       void *stream);
+/* The owner function itself (host-callable, same arithmetic as the kernel). */
+int32_t tmp_key_owner(int32_t key, int32_t n_parts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEMPO_HIP_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of libtempo_hip.so (declarations: include/tempo_hip.h).
+
+There is no CPU fallback: loading fails loudly when the library has not been built
+(`make -C tempo_amd/csrc`, or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtempo_hip.so")
+
+TMP_MAX_MASKS = 16
+TMP_MAX_TAPS = 1024
+TMP_MAX_FEATURES = 64
+TMP_MAX_COLS = 64
+FUNC_CODES = {"floor": 0, "min": 1, "max": 2, "mean": 3, "ceil": 4}
+
+_vp = C.c_void_p
+
+
+class SortArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("ts_unit", C.c_int32), ("seq", _vp), ("seq_valid", _vp), ("out_perm", _vp)]
+
+
+class AsofArgs(C.Structure):
+    _fields_ = [("n_left", C.c_int64), ("n_right", C.c_int64), ("key_left", _vp),
+                ("ts_left", _vp), ("key_right", _vp), ("ts_right", _vp), ("seq_right", _vp),
+                ("seq_right_valid", _vp), ("n_keys", C.c_int32), ("ts_is_seconds", C.c_int32),
+                ("n_masks", C.c_int32), ("masks", C.POINTER(_vp)), ("skew", C.c_int32),
+                ("v_is_int", C.c_int32), ("ts_partition_val", C.c_double),
+                ("one_minus_fraction", C.c_double), ("out_row_idx", _vp), ("out_mask_idx", _vp),
+                ("out_missing", _vp)]
+
+
+class RangeStatsArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("ts_is_seconds", C.c_int32), ("x_is_i64", C.c_int32), ("x", _vp),
+                ("x_valid", _vp), ("range_back_secs", C.c_int64), ("out_perm", _vp),
+                ("out_mean", _vp), ("out_count", _vp), ("out_min", _vp), ("out_max", _vp),
+                ("out_sum", _vp), ("out_stddev", _vp), ("out_zscore", _vp), ("out_valid", _vp)]
+
+
+class EmaArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("ts_is_seconds", C.c_int32), ("seq", _vp), ("seq_valid", _vp), ("x", _vp),
+                ("x_valid", _vp), ("n_taps", C.c_int32), ("weights", C.POINTER(C.c_double)),
+                ("out_perm", _vp), ("out_ema", _vp)]
+
+
+class LookbackArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("ts_is_seconds", C.c_int32), ("seq", _vp), ("seq_valid", _vp),
+                ("n_feat", C.c_int32), ("x", C.POINTER(_vp)), ("x_valid", C.POINTER(_vp)),
+                ("lookback", C.c_int32), ("exact_size", C.c_int32), ("out_rows", _vp),
+                ("out_len", _vp), ("out_feat", _vp), ("out_feat_valid", _vp), ("out_count", _vp)]
+
+
+class ResampleArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("dur_us", C.c_int64), ("func", C.c_int32), ("n_cols", C.c_int32),
+                ("cols", C.POINTER(_vp)), ("col_is_i64", C.POINTER(C.c_int32)),
+                ("col_valid", C.POINTER(_vp)), ("out_key", _vp), ("out_start", _vp),
+                ("out_f64", _vp), ("out_i64", _vp), ("out_valid", _vp), ("out_row", _vp),
+                ("out_count", _vp)]
+
+
+class PartitionArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_parts", C.c_int32), ("out_perm", _vp),
+                ("out_counts", _vp)]
+
+
+# every symbol include/tempo_hip.h declares: name -> (restype, argtypes)
+_OP = lambda argt: (C.c_int, [C.POINTER(argt), _vp, C.c_size_t, _vp])
+_WS = lambda argt: (C.c_size_t, [C.POINTER(argt)])
+SYMBOLS = {
+    "tmp_abi_version": (C.c_int, []),
+    "tmp_last_error": (C.c_char_p, []),
+    "tmp_sort_order_workspace_bytes": _WS(SortArgs),
+    "tmp_sort_order": _OP(SortArgs),
+    "tmp_asof_join_workspace_bytes": _WS(AsofArgs),
+    "tmp_asof_join": _OP(AsofArgs),
+    "tmp_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp]),
+    "tmp_range_stats_workspace_bytes": _WS(RangeStatsArgs),
+    "tmp_range_stats": _OP(RangeStatsArgs),
+    "tmp_ema_workspace_bytes": _WS(EmaArgs),
+    "tmp_ema": _OP(EmaArgs),
+    "tmp_lookback_workspace_bytes": _WS(LookbackArgs),
+    "tmp_lookback": _OP(LookbackArgs),
+    "tmp_resample_workspace_bytes": _WS(ResampleArgs),
+    "tmp_resample": _OP(ResampleArgs),
+    "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
+    "tmp_hash_partition": _OP(PartitionArgs),
+    "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),
+}
+
+_LIB = None
+
+
+class TempoHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it is missing (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TempoHipError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(hipcc, gfx950). tempo_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the build lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if handle.tmp_abi_version() != 1:
+            raise TempoHipError("libtempo_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tmp_last_error().decode("utf-8", "replace")
+        if rc == -4:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise TempoHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr_array(ptrs):
+    arr = (_vp * max(len(ptrs), 1))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

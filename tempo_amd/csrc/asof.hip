@@ -1,0 +1,374 @@
+// AS-OF join match.  Replaces the union + running last(col, ignorenulls) window of
+// python/tempo/tsdf.py:463-560 / :111-162 and the bracket rule of :164-190.
+//
+// Both sides are ordered independently by (key, ts[, seq]) into 64-bit sort words that share
+// one bit layout; the per-column validity bits of the right side ride in the low bits of its
+// sort words.  Then:
+//   1. a wave-ballot prefix scan over the ordered right side gives, for every position and
+//      mask, the last position at or before it whose mask bit is set;
+//   2. every left row binary-searches its position in the ordered right side (search range
+//      narrowed per block), applies the key / bracket visibility tests and scatters the
+//      matched right row ids back to the left table's own row order.
+#include <string.h>
+
+#include "common.h"
+
+namespace tmp {
+
+struct AsofPlan {
+  OrderBuffers lb, rb;
+  int32_t *lastnn;   // [n_masks][n_right]
+  int32_t *unit_agg; // [n_masks][kUnits]
+};
+
+constexpr int kUnits = 4096;     // waves that each scan one contiguous slice of the right side
+constexpr int kUnitBlock = 256;  // 4 waves per block
+constexpr int kRowsPerIter = 64 * 4;
+
+struct ScanGeom {
+  int units;
+  int64_t rows_per_unit;
+};
+
+static ScanGeom scan_geom(int64_t n) {
+  ScanGeom g;
+  int64_t iters = (n + kRowsPerIter - 1) / kRowsPerIter;
+  if (iters < 1) iters = 1;
+  int64_t per = (iters + kUnits - 1) / kUnits;
+  g.rows_per_unit = per * kRowsPerIter;
+  g.units = (int)((n + g.rows_per_unit - 1) / g.rows_per_unit);
+  if (g.units < 1) g.units = 1;
+  return g;
+}
+
+// Phase 1: per unit and mask, the last position whose bit is set (or -1).
+__global__ __launch_bounds__(kUnitBlock) void lastnn_reduce_kernel(const uint64_t *comp, int64_t n,
+                                                                   int n_masks,
+                                                                   int64_t rows_per_unit, int units,
+                                                                   int32_t *unit_agg) {
+  int unit = blockIdx.x * (kUnitBlock / 64) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (unit >= units) return;
+  int64_t begin = (int64_t)unit * rows_per_unit;
+  int64_t end = begin + rows_per_unit < n ? begin + rows_per_unit : n;
+  int32_t last[TMP_MAX_MASKS];
+#pragma unroll
+  for (int m = 0; m < TMP_MAX_MASKS; ++m) last[m] = -1;
+  for (int64_t base = begin; base < end; base += kRowsPerIter) {
+    uint64_t w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t i = base + r * 64 + lane;
+      w[r] = i < end ? comp[i] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int m = 0; m < TMP_MAX_MASKS; ++m) {
+        if (m < n_masks) {
+          uint64_t bal = __ballot((w[r] >> m) & 1ull);
+          if (bal) last[m] = (int32_t)(base + r * 64 + 63 - __clzll((long long)bal));
+        }
+      }
+    }
+  }
+  if (lane == 0)
+    for (int m = 0; m < n_masks; ++m) unit_agg[(size_t)m * kUnits + unit] = last[m];
+}
+
+// Phase 2: exclusive prefix-max over the units of one mask (grid.x = n_masks, 1024 threads).
+__global__ __launch_bounds__(1024) void lastnn_carry_kernel(int32_t *unit_agg, int units) {
+  __shared__ int32_t wave_max_s[16];
+  int32_t *agg = unit_agg + (size_t)blockIdx.x * kUnits;
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t v[4], m = -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int u = tid * 4 + k;
+    v[k] = u < units ? agg[u] : -1;
+    m = v[k] > m ? v[k] : m;
+  }
+  int32_t inc = m;
+  for (int o = 1; o < 64; o <<= 1) {
+    int32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = t > inc ? t : inc;
+  }
+  if (lane == 63) wave_max_s[wave] = inc;
+  __syncthreads();
+  int32_t run = -1;
+  for (int w = 0; w < wave; ++w) run = wave_max_s[w] > run ? wave_max_s[w] : run;
+  int32_t prev = __shfl_up(inc, 1, 64);
+  if (lane > 0) run = prev > run ? prev : run;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int u = tid * 4 + k;
+    if (u < units) agg[u] = run;
+    run = v[k] > run ? v[k] : run;
+  }
+}
+
+// Phase 3: write lastnn[m][j] = last position <= j whose mask bit m is set, or -1.
+__global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t *comp, int64_t n,
+                                                                 int n_masks,
+                                                                 int64_t rows_per_unit, int units,
+                                                                 const int32_t *unit_agg,
+                                                                 int32_t *lastnn) {
+  int unit = blockIdx.x * (kUnitBlock / 64) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (unit >= units) return;
+  int64_t begin = (int64_t)unit * rows_per_unit;
+  int64_t end = begin + rows_per_unit < n ? begin + rows_per_unit : n;
+  int32_t carry[TMP_MAX_MASKS];
+#pragma unroll
+  for (int m = 0; m < TMP_MAX_MASKS; ++m)
+    carry[m] = m < n_masks ? unit_agg[(size_t)m * kUnits + unit] : -1;
+  const uint64_t le_mask = ~0ull >> (63 - lane);
+  for (int64_t base = begin; base < end; base += kRowsPerIter) {
+    uint64_t w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t i = base + r * 64 + lane;
+      w[r] = i < end ? comp[i] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t i = base + r * 64 + lane;
+#pragma unroll
+      for (int m = 0; m < TMP_MAX_MASKS; ++m) {
+        if (m < n_masks) {
+          uint64_t bal = __ballot((w[r] >> m) & 1ull);
+          uint64_t le = bal & le_mask;
+          int32_t j = le ? (int32_t)(base + r * 64 + 63 - __clzll((long long)le)) : carry[m];
+          if (i < end) lastnn[(size_t)m * n + i] = j;
+          if (bal) carry[m] = (int32_t)(base + r * 64 + 63 - __clzll((long long)bal));
+        }
+      }
+    }
+  }
+}
+
+// Bracket rule of tsdf.py:178-185, same IEEE operations in the same order (the library is
+// built with -ffp-contract=off).  Spark casts double -> int by truncation, saturating, NaN->0.
+__device__ __forceinline__ int32_t spark_d2i(double x) {
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (int32_t)0x80000000;
+  return (int32_t)x;
+}
+
+struct SkewParams {
+  int enabled;
+  int v_is_int;
+  int ts_is_seconds;
+  double v;
+  double one_minus_fraction;
+};
+
+__device__ __forceinline__ void bracket_of(int64_t ts, const SkewParams &sp, double *part,
+                                           double *rem) {
+  double d = sp.ts_is_seconds ? (double)ts : (double)ts / 1000000.0;
+  int32_t q = spark_d2i(d / sp.v);
+  double p = sp.v_is_int ? (double)(int32_t)((uint32_t)(int32_t)sp.v * (uint32_t)q) : sp.v * (double)q;
+  *part = p;
+  *rem = (d - p) / sp.v;
+}
+
+__device__ __forceinline__ bool bracket_visible(int64_t ts_right, double part_left,
+                                                const SkewParams &sp) {
+  double pr, rr;
+  bracket_of(ts_right, sp, &pr, &rr);
+  if (pr == part_left) return true;
+  double nxt = sp.v_is_int ? (double)(int32_t)((uint32_t)(int32_t)pr + (uint32_t)(int32_t)sp.v)
+                           : pr + sp.v;
+  return nxt == part_left && rr >= sp.one_minus_fraction;
+}
+
+// Number of right rows ordered at or before the left sort word `key` (low bits dropped).
+__device__ __forceinline__ int64_t upper_bound(const uint64_t *comp, int64_t lo, int64_t hi,
+                                               uint64_t key, int low_bits) {
+  while (lo < hi) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    if ((comp[mid] >> low_bits) <= key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+constexpr int kMergeRows = 4;  // left rows per thread
+
+__global__ __launch_bounds__(kBlock) void asof_merge_kernel(
+    const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
+    const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
+    SkewParams sp, int32_t *out_row_idx, int32_t *out_mask_idx, int32_t *out_missing) {
+  __shared__ int64_t bounds[2];
+  const int low = lay.low_bits;
+  int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
+  int64_t tile_end = tile + kBlock * kMergeRows < n_left ? tile + kBlock * kMergeRows : n_left;
+  // Waves 0 and 1 each find one end of the block's search range; every lane of the wave runs
+  // the same search (a wave-uniform branch), lane 0 publishes it.
+  const int wave = threadIdx.x >> 6;
+  if (wave < 2) {
+    uint64_t k = (wave == 0 ? comp_l[tile] : comp_l[tile_end - 1]) >> low;
+    int64_t ub = upper_bound(comp_r, 0, n_right, k, low);
+    if (wave == 0) ub = ub > 0 ? ub - 1 : 0;  // the row just before the first position stays reachable
+    if ((threadIdx.x & 63) == 0) bounds[wave] = ub;
+  }
+  __syncthreads();
+  const int64_t blo = bounds[0], bhi = bounds[1];
+  int miss_row = 0;
+  uint32_t miss_mask = 0;
+  for (int r = 0; r < kMergeRows; ++r) {
+    int64_t i = tile + r * kBlock + threadIdx.x;
+    if (i >= tile_end) break;
+    uint64_t wl = comp_l[i];
+    uint64_t kl = wl >> low;
+    int64_t pos = upper_bound(comp_r, blo, bhi, kl, low);
+    int64_t jr = pos - 1;
+    uint32_t key_l = lay.key_of(wl);
+    bool same = jr >= 0 && lay.key_of(comp_r[jr]) == key_l;
+    double part_l = 0.0, rem_l;
+    if (sp.enabled) bracket_of(lay.prim_of(wl), sp, &part_l, &rem_l);
+    uint32_t dst = perm_l[i];
+    int32_t row_src = -1;
+    if (same && (!sp.enabled || bracket_visible(lay.prim_of(comp_r[jr]), part_l, sp)))
+      row_src = (int32_t)perm_r[jr];
+    if (out_row_idx) out_row_idx[dst] = row_src;
+    miss_row |= row_src < 0;
+    for (int m = 0; m < n_masks; ++m) {
+      int32_t src = -1;
+      if (same) {
+        int32_t j = lastnn[(size_t)m * n_right + jr];
+        if (j >= 0) {
+          uint64_t wr = comp_r[j];
+          if (lay.key_of(wr) == key_l &&
+              (!sp.enabled || bracket_visible(lay.prim_of(wr), part_l, sp)))
+            src = (int32_t)perm_r[j];
+        }
+      }
+      out_mask_idx[(size_t)m * n_left + dst] = src;
+      miss_mask |= (uint32_t)(src < 0) << m;
+    }
+  }
+  if (__any(miss_row) && (threadIdx.x & 63) == 0) atomicOr(&out_missing[0], 1);
+  for (int m = 0; m < n_masks; ++m) {
+    int any = __any((miss_mask >> m) & 1u);
+    if (any && (threadIdx.x & 63) == 0) atomicOr(&out_missing[1 + m], 1);
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
+  order_plan(a->n_left, ws, &p->lb);
+  order_plan(a->n_right, ws, &p->rb);
+  size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
+  p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
+  p->unit_agg = ws.take<int32_t>(nm * kUnits);
+}
+
+}  // namespace tmp
+
+using namespace tmp;
+
+static int asof_validate(const tmp_asof_args *a) {
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_asof_join: null args");
+  TMP_REQUIRE(a->n_left >= 0 && a->n_right >= 0 && a->n_left < (1ll << 31) && a->n_right < (1ll << 31),
+              TMP_EINVAL, "tmp_asof_join: row counts must be in [0, 2^31)");
+  TMP_REQUIRE(a->n_masks >= 0 && a->n_masks <= TMP_MAX_MASKS, TMP_EINVAL,
+              "tmp_asof_join: n_masks must be in [0, %d]", TMP_MAX_MASKS);
+  TMP_REQUIRE(a->n_left == 0 || a->n_right == 0 ||
+                  (a->key_left == nullptr) == (a->key_right == nullptr), TMP_EINVAL,
+              "tmp_asof_join: key columns must be given for both sides or neither");
+  TMP_REQUIRE(a->n_left == 0 || a->ts_left, TMP_EINVAL, "tmp_asof_join: ts_left is null");
+  TMP_REQUIRE(a->n_right == 0 || a->ts_right, TMP_EINVAL, "tmp_asof_join: ts_right is null");
+  TMP_REQUIRE(a->n_masks == 0 || (a->masks && a->out_mask_idx), TMP_EINVAL,
+              "tmp_asof_join: masks/out_mask_idx missing");
+  TMP_REQUIRE(a->out_missing, TMP_EINVAL, "tmp_asof_join: out_missing is null");
+  if (a->skew) {
+    TMP_REQUIRE(a->ts_partition_val == a->ts_partition_val && a->ts_partition_val != 0.0, TMP_EINVAL,
+                "tmp_asof_join: ts_partition_val must be a non-zero number");
+  }
+  return TMP_OK;
+}
+
+extern "C" size_t tmp_asof_join_workspace_bytes(const tmp_asof_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  AsofPlan p;
+  asof_plan(a, ws, &p);
+  return ws.off;
+}
+
+extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+  clear_error();
+  TMP_TRY(asof_validate(a));
+  hipStream_t st = (hipStream_t)stream;
+  TMP_CHECK_HIP(hipMemsetAsync(a->out_missing, 0, sizeof(int32_t) * (1 + a->n_masks), st));
+  if (a->n_left == 0) return TMP_OK;
+  Workspace ws(workspace, workspace_bytes);
+  AsofPlan p;
+  asof_plan(a, ws, &p);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE,
+              "tmp_asof_join: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+  if (a->n_right == 0) {  // nothing to match: every index is -1, everything is missing
+    int grid = grid_for(a->n_left, kBlock * 4, 8192);
+    if (a->out_row_idx)
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(kBlock), 0, st, a->out_row_idx, a->n_left, -1);
+    if (a->n_masks)
+      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(kBlock), 0, st, a->out_mask_idx,
+                         a->n_left * a->n_masks, -1);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, a->out_missing, 1 + a->n_masks, 1);
+    TMP_CHECK_HIP(hipGetLastError());
+    return TMP_OK;
+  }
+
+  OrderSpec ls, rs;
+  memset(&ls, 0, sizeof(ls));
+  memset(&rs, 0, sizeof(rs));
+  ls.n = a->n_left; ls.key = a->key_left; ls.n_keys = a->n_keys; ls.ts = a->ts_left; ls.prim_div = 1;
+  rs.n = a->n_right; rs.key = a->key_right; rs.n_keys = a->n_keys; rs.ts = a->ts_right; rs.prim_div = 1;
+  rs.seq = a->seq_right; rs.seq_valid = a->seq_right_valid;
+  rs.n_masks = a->n_masks;
+  for (int m = 0; m < a->n_masks; ++m) rs.masks[m] = a->masks[m];
+
+  // ranges of both sides, one host read each, then one shared bit layout
+  TMP_TRY(order_scan_ranges(ls, p.lb, st));
+  TMP_TRY(order_scan_ranges(rs, p.rb, st));
+  RangeInfo rl, rr;
+  TMP_TRY(order_read_ranges(p.lb, &rl, st));
+  TMP_TRY(order_read_ranges(p.rb, &rr, st));
+  RangeInfo both = rr;
+  both.prim_min = rl.prim_min < rr.prim_min ? rl.prim_min : rr.prim_min;
+  both.prim_max = rl.prim_max > rr.prim_max ? rl.prim_max : rr.prim_max;
+  Layout lay;
+  TMP_TRY(order_make_layout(rs, both, a->n_masks, &lay));
+  OrderResult lo, ro;
+  TMP_TRY(order_build(ls, lay, rl.unsorted == 0, p.lb, &lo, st));
+  TMP_TRY(order_build(rs, lay, rr.unsorted == 0, p.rb, &ro, st));
+
+  if (a->n_masks > 0) {
+    ScanGeom g = scan_geom(a->n_right);
+    int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
+    hipLaunchKernelGGL(lastnn_reduce_kernel, dim3(blocks), dim3(kUnitBlock), 0, st, ro.comp,
+                       a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg);
+    hipLaunchKernelGGL(lastnn_carry_kernel, dim3(a->n_masks), dim3(1024), 0, st, p.unit_agg, g.units);
+    hipLaunchKernelGGL(lastnn_scan_kernel, dim3(blocks), dim3(kUnitBlock), 0, st, ro.comp,
+                       a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg, p.lastnn);
+  }
+  SkewParams sp;
+  sp.enabled = a->skew != 0;
+  sp.v_is_int = a->v_is_int;
+  sp.ts_is_seconds = a->ts_is_seconds;
+  sp.v = a->ts_partition_val;
+  sp.one_minus_fraction = a->one_minus_fraction;
+  int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
+  hipLaunchKernelGGL(asof_merge_kernel, dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+                     ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_row_idx,
+                     a->out_mask_idx, a->out_missing);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}

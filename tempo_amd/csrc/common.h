@@ -1,0 +1,150 @@
+// Shared host/device helpers of libtempo_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "tempo_hip.h"
+
+namespace tmp {
+
+void set_error(const char *fmt, ...);
+void clear_error();
+
+#define TMP_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::tmp::set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return TMP_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+#define TMP_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      ::tmp::set_error(__VA_ARGS__);  \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define TMP_TRY(expr)          \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != TMP_OK) return rc_; \
+  } while (0)
+
+// Bump allocator over the caller's workspace.  With base == nullptr it only measures, so the
+// same planning code serves tmp_*_workspace_bytes and the real call.
+struct Workspace {
+  char *base;
+  size_t size;
+  size_t off;
+  Workspace(void *b, size_t s) : base((char *)b), size(s), off(0) {}
+  template <typename T>
+  T *take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    size_t at = off;
+    off += bytes;
+    if (!base) return nullptr;
+    if (off > size) return nullptr;
+    return (T *)(base + at);
+  }
+  bool measuring() const { return base == nullptr; }
+  bool overflow() const { return base != nullptr && off > size; }
+};
+
+inline int bits_for(uint64_t max_value) {  // bits needed to hold values in [0, max_value]
+  int b = 0;
+  while (max_value) { ++b; max_value >>= 1; }
+  return b;
+}
+
+// Bit layout of the 64-bit sort word ("composite"), most significant field first:
+//   [ key id | primary order key - prim_min | sequence field | low bits ]
+// primary = ts, or floor(ts / prim_div); sequence field = 0 for NULL, seq - seq_min + 1
+// otherwise (NULLS FIRST); the low bits are carried through the sort but never compared.
+struct Layout {
+  int low_bits;
+  int seq_bits;
+  int prim_bits;
+  int key_bits;
+  int64_t prim_min;
+  int64_t seq_min;
+  int64_t prim_div;
+  __host__ __device__ int seq_shift() const { return low_bits; }
+  __host__ __device__ int prim_shift() const { return low_bits + seq_bits; }
+  __host__ __device__ int key_shift() const { return low_bits + seq_bits + prim_bits; }
+  __host__ __device__ int total_bits() const { return low_bits + seq_bits + prim_bits + key_bits; }
+  __host__ __device__ uint64_t prim_mask() const {
+    return prim_bits >= 64 ? ~0ull : ((1ull << prim_bits) - 1);
+  }
+  __device__ int64_t prim_of(uint64_t comp) const {
+    return prim_min + (int64_t)((comp >> prim_shift()) & prim_mask());
+  }
+  __device__ uint32_t key_of(uint64_t comp) const {
+    return key_bits == 0 ? 0u : (uint32_t)(comp >> key_shift());
+  }
+};
+
+// Values the ordering step reads back from the device before it can lay out the sort word.
+struct RangeInfo {
+  int64_t prim_min;
+  int64_t prim_max;
+  int64_t seq_min;
+  int64_t seq_max;
+  int32_t unsorted;
+  int32_t pad;
+};
+
+struct OrderSpec {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int64_t prim_div;  // 1, or 1000000 for timestamp.cast("long")
+  const int64_t *seq;
+  const uint8_t *seq_valid;
+  int n_masks;
+  const uint8_t *masks[TMP_MAX_MASKS];
+};
+
+struct OrderBuffers {
+  uint64_t *comp[2];
+  uint32_t *idx[2];
+  uint32_t *counts;
+  RangeInfo *range;  // device
+};
+
+struct OrderResult {
+  const uint64_t *comp;  // sorted sort words
+  const uint32_t *perm;  // perm[p] = input row at sorted position p
+};
+
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b);
+int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st);
+int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st);
+int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layout *out);
+int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, OrderBuffers &b,
+                OrderResult *res, hipStream_t st);
+// One-call form for ops that order a single table.
+int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
+                 hipStream_t st);
+
+__device__ __forceinline__ int64_t floordiv_i64(int64_t a, int64_t b) {
+  int64_t q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}
+
+constexpr int kBlock = 256;
+inline int grid_for(int64_t n, int per_block, int max_grid = 1 << 20) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > max_grid) g = max_grid;
+  return (int)g;
+}
+
+}  // namespace tmp

@@ -1,0 +1,457 @@
+// Ordering step shared by every op: (key, primary[, seq]) -> 64-bit sort word -> stable LSD
+// radix sort of (sort word, row id) pairs.  Replaces Spark's Exchange + SortExec in front of
+// WindowExec / aggregates (python/tempo/tsdf.py:117-121, :563-572; resample.py:63).
+#include <string.h>
+
+#include "common.h"
+
+namespace tmp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+
+// ------------------------------------------------------------------------------------------
+// Pass 0: value ranges + "already in order" test, one streaming read of key/ts/seq.
+// ------------------------------------------------------------------------------------------
+__global__ void range_init_kernel(RangeInfo *r) {
+  r->prim_min = INT64_MAX;
+  r->prim_max = INT64_MIN;
+  r->seq_min = INT64_MAX;
+  r->seq_max = INT64_MIN;
+  r->unsorted = 0;
+  r->pad = 0;
+}
+
+__device__ __forceinline__ int64_t wave_min(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    int64_t t = __shfl_down(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_max(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    int64_t t = __shfl_down(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int32_t *key,
+                                                            const int64_t *ts, int64_t div,
+                                                            const int64_t *seq,
+                                                            const uint8_t *seq_valid,
+                                                            RangeInfo *out) {
+  int64_t pmin = INT64_MAX, pmax = INT64_MIN, smin = INT64_MAX, smax = INT64_MIN;
+  int bad = 0;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
+    pmin = p < pmin ? p : pmin;
+    pmax = p > pmax ? p : pmax;
+    bool sv = false;
+    int64_t s = 0;
+    if (seq) {
+      sv = !seq_valid || seq_valid[i];
+      if (sv) {
+        s = seq[i];
+        smin = s < smin ? s : smin;
+        smax = s > smax ? s : smax;
+      }
+    }
+    if (i > 0) {  // lexicographic (key, primary, seq NULLS FIRST) against the previous row
+      int32_t k0 = key ? key[i - 1] : 0, k1 = key ? key[i] : 0;
+      if (k0 != k1) bad |= k0 > k1;
+      else {
+        int64_t p0 = div == 1 ? ts[i - 1] : floordiv_i64(ts[i - 1], div);
+        if (p0 != p) bad |= p0 > p;
+        else if (seq) {
+          bool sv0 = !seq_valid || seq_valid[i - 1];
+          if (sv0 != sv) bad |= sv0;            // previous non-NULL, this one NULL
+          else if (sv) bad |= seq[i - 1] > s;
+        }
+      }
+    }
+  }
+  pmin = wave_min(pmin);
+  pmax = wave_max(pmax);
+  smin = wave_min(smin);
+  smax = wave_max(smax);
+  bad = __any(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (pmin != INT64_MAX) atomicMin((long long *)&out->prim_min, (long long)pmin);
+    if (pmax != INT64_MIN) atomicMax((long long *)&out->prim_max, (long long)pmax);
+    if (smin != INT64_MAX) atomicMin((long long *)&out->seq_min, (long long)smin);
+    if (smax != INT64_MIN) atomicMax((long long *)&out->seq_max, (long long)smax);
+    if (bad) atomicOr(&out->unsorted, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Pass 1: build the sort word and the identity row ids.
+// ------------------------------------------------------------------------------------------
+struct MaskPtrs {
+  const uint8_t *p[TMP_MAX_MASKS];
+};
+
+__global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, const int32_t *key,
+                                                           const int64_t *ts,
+                                                           const int64_t *seq,
+                                                           const uint8_t *seq_valid, Layout lay,
+                                                           int n_masks, MaskPtrs masks,
+                                                           uint64_t *comp, uint32_t *idx) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int64_t p = lay.prim_div == 1 ? ts[i] : floordiv_i64(ts[i], lay.prim_div);
+    uint64_t w = (uint64_t)(p - lay.prim_min) << lay.prim_shift();
+    if (lay.key_bits) w |= (uint64_t)(uint32_t)key[i] << lay.key_shift();
+    if (lay.seq_bits && seq) {
+      bool sv = !seq_valid || seq_valid[i];
+      if (sv) w |= (uint64_t)(seq[i] - lay.seq_min + 1) << lay.seq_shift();
+    }
+    for (int m = 0; m < n_masks; ++m)
+      if (!masks.p[m] || masks.p[m][i]) w |= 1ull << m;
+    comp[i] = w;
+    if (idx) idx[i] = (uint32_t)i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LSD radix sort of (sort word, row id) pairs, 8-bit digits, three kernels per digit:
+//   histogram per block -> exclusive scan of the [digit][block] table -> stable scatter.
+// A block owns a contiguous run of tiles; inside a tile the rank of a row among the rows with
+// the same digit comes from wave-wide ballots (64 lanes) plus per-wave LDS counters, and the
+// tile is first reordered in LDS so that global stores go out in runs of equal digit.
+// ------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_MAX_GRID = 1024;
+constexpr int RS_RADIX = 256;
+
+struct SortGeom {
+  int grid;
+  int tiles_per_block;
+};
+
+static SortGeom sort_geom(int64_t n) {
+  int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  if (tiles < 1) tiles = 1;
+  SortGeom g;
+  g.tiles_per_block = (int)((tiles + RS_MAX_GRID - 1) / RS_MAX_GRID);
+  g.grid = (int)((tiles + g.tiles_per_block - 1) / g.tiles_per_block);
+  return g;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
+                                                                int shift, uint32_t mask,
+                                                                int tiles_per_block,
+                                                                uint32_t *counts) {
+  __shared__ uint32_t hist[RS_WAVES][RS_RADIX];
+  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  int64_t begin = (int64_t)blockIdx.x * tiles_per_block * RS_TILE;
+  int64_t end = begin + (int64_t)tiles_per_block * RS_TILE;
+  if (end > n) end = n;
+  int wave = threadIdx.x >> 6;
+  for (int64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
+    uint32_t d = (uint32_t)(keys[i] >> shift) & mask;
+    atomicAdd(&hist[wave][d], 1u);
+  }
+  __syncthreads();
+  uint32_t c = 0;
+  for (int w = 0; w < RS_WAVES; ++w) c += hist[w][threadIdx.x];
+  counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = c;
+}
+
+// Exclusive scan of `total` uint32 counters in place, one block.
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int total) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < total; base += 4096) {
+    int i = base + tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i + k < total) ? counts[i + k] : 0u;
+    uint32_t s = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = s;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wp = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      uint32_t t = wave_tot[w];
+      if (w < wave) wp += t;
+      tot += t;
+    }
+    uint32_t run = carry_s + wp + (inc - s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < total) counts[i + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 0) carry_s += tot;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
+    const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
+    int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets) {
+  __shared__ uint64_t skey[RS_TILE];
+  __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
+  __shared__ uint32_t dstart[RS_RADIX];
+  __shared__ uint32_t goff[RS_RADIX];
+  __shared__ uint32_t wtot[RS_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
+  volatile uint32_t *wh = &whist[wave][0];
+  for (int t = 0; t < tiles_per_block; ++t) {
+    int64_t tile_base = ((int64_t)blockIdx.x * tiles_per_block + t) * RS_TILE;
+    if (tile_base >= n) break;
+    int tile_n = (int)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
+    for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    uint64_t k[RS_ITEMS];
+    uint32_t v[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+      bool valid = pos < tile_n;
+      k[it] = valid ? kin[tile_base + pos] : 0ull;
+      v[it] = valid ? vin[tile_base + pos] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+      bool valid = pos < tile_n;
+      uint32_t d = (uint32_t)(k[it] >> shift) & mask;
+      uint64_t peers = __ballot(valid);
+      for (int b = 0; b < nbits; ++b) {
+        uint64_t bal = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? bal : ~bal;
+      }
+      uint32_t prior = wh[d];
+      uint32_t cnt = (uint32_t)__popcll(peers);
+      bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
+      if (leader) wh[d] = prior + cnt;
+      rank[it] = prior + (uint32_t)__popcll(peers & lt_mask);
+    }
+    __syncthreads();
+    // digit `tid`: exclusive prefix of its count over the waves, then over the digits
+    uint32_t cnt_d = 0;
+    for (int w = 0; w < RS_WAVES; ++w) {
+      uint32_t c = whist[w][tid];
+      whist[w][tid] = cnt_d;
+      cnt_d += c;
+    }
+    uint32_t inc = cnt_d;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t tt = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += tt;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t wp = 0;
+    for (int w = 0; w < wave; ++w) wp += wtot[w];
+    dstart[tid] = wp + inc - cnt_d;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+      if (pos < tile_n) {
+        uint32_t d = (uint32_t)(k[it] >> shift) & mask;
+        uint32_t p = dstart[d] + whist[wave][d] + rank[it];
+        skey[p] = k[it];
+        sval[p] = v[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+      int p = tid + j * RS_THREADS;
+      if (p < tile_n) {
+        uint64_t kk = skey[p];
+        uint32_t d = (uint32_t)(kk >> shift) & mask;
+        uint32_t g = goff[d] + ((uint32_t)p - dstart[d]);
+        kout[g] = kk;
+        vout[g] = sval[p];
+      }
+    }
+    __syncthreads();
+    goff[tid] += cnt_d;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
+  size_t cnt = (size_t)(n > 0 ? n : 1);
+  b->comp[0] = ws.take<uint64_t>(cnt);
+  b->comp[1] = ws.take<uint64_t>(cnt);
+  b->idx[0] = ws.take<uint32_t>(cnt);
+  b->idx[1] = ws.take<uint32_t>(cnt);
+  b->counts = ws.take<uint32_t>((size_t)RS_RADIX * RS_MAX_GRID);
+  b->range = ws.take<RangeInfo>(1);
+}
+
+int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
+  hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(1), 0, st, b.range);
+  if (s.n > 0) {
+    int grid = grid_for(s.n, kBlock * 8, 4096);
+    hipLaunchKernelGGL(range_scan_kernel, dim3(grid), dim3(kBlock), 0, st, s.n, s.key, s.ts,
+                       s.prim_div, s.seq, s.seq_valid, b.range);
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
+
+int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st) {
+  TMP_CHECK_HIP(hipMemcpyAsync(host, b.range, sizeof(RangeInfo), hipMemcpyDeviceToHost, st));
+  TMP_CHECK_HIP(hipStreamSynchronize(st));
+  return TMP_OK;
+}
+
+int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layout *out) {
+  Layout l;
+  l.low_bits = low_bits;
+  l.prim_div = s.prim_div;
+  l.prim_min = r.prim_min <= r.prim_max ? r.prim_min : 0;
+  uint64_t prange = r.prim_min <= r.prim_max ? (uint64_t)r.prim_max - (uint64_t)r.prim_min : 0;
+  l.prim_bits = bits_for(prange);
+  l.seq_bits = 0;
+  l.seq_min = 0;
+  if (s.seq) {
+    if (r.seq_min <= r.seq_max) {
+      l.seq_min = r.seq_min;
+      uint64_t srange = (uint64_t)r.seq_max - (uint64_t)r.seq_min;
+      TMP_REQUIRE(srange < (1ull << 62), TMP_EUNSUPPORTED, "sequence column range too wide");
+      l.seq_bits = bits_for(srange + 1);
+    } else {
+      l.seq_bits = 1;  // every sequence value is NULL
+    }
+  }
+  l.key_bits = s.key ? bits_for((uint64_t)(s.n_keys > 1 ? s.n_keys - 1 : 0)) : 0;
+  TMP_REQUIRE(l.total_bits() <= 64, TMP_EUNSUPPORTED,
+              "sort word needs %d bits (key %d + time %d + sequence %d + masks %d) > 64",
+              l.total_bits(), l.key_bits, l.prim_bits, l.seq_bits, l.low_bits);
+  *out = l;
+  return TMP_OK;
+}
+
+int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, OrderBuffers &b,
+                OrderResult *res, hipStream_t st) {
+  res->comp = b.comp[0];
+  res->perm = b.idx[0];
+  if (s.n <= 0) return TMP_OK;
+  MaskPtrs mp;
+  for (int m = 0; m < TMP_MAX_MASKS; ++m) mp.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
+  int grid = grid_for(s.n, kBlock * 4, 8192);
+  hipLaunchKernelGGL(make_comp_kernel, dim3(grid), dim3(kBlock), 0, st, s.n, s.key, s.ts, s.seq,
+                     s.seq_valid, lay, s.n_masks, mp, b.comp[0], b.idx[0]);
+  TMP_CHECK_HIP(hipGetLastError());
+  if (already_sorted) return TMP_OK;
+  SortGeom g = sort_geom(s.n);
+  int cur = 0;
+  for (int lo = lay.low_bits; lo < lay.total_bits(); lo += 8) {
+    int nbits = lay.total_bits() - lo < 8 ? lay.total_bits() - lo : 8;
+    uint32_t mask = (1u << nbits) - 1;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(g.grid), dim3(RS_THREADS), 0, st, b.comp[cur], s.n,
+                       lo, mask, g.tiles_per_block, b.counts);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, b.counts,
+                       RS_RADIX * g.grid);
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(g.grid), dim3(RS_THREADS), 0, st, b.comp[cur],
+                       b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], s.n, lo, mask, nbits,
+                       g.tiles_per_block, b.counts);
+    cur ^= 1;
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  res->comp = b.comp[cur];
+  res->perm = b.idx[cur];
+  return TMP_OK;
+}
+
+int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
+                 hipStream_t st) {
+  TMP_TRY(order_scan_ranges(s, b, st));
+  RangeInfo r;
+  TMP_TRY(order_read_ranges(b, &r, st));
+  TMP_TRY(order_make_layout(s, r, s.n_masks, lay));
+  return order_build(s, *lay, r.unsorted == 0, b, res, st);
+}
+
+}  // namespace tmp
+
+using namespace tmp;
+
+extern "C" int tmp_abi_version(void) { return TMP_ABI_VERSION; }
+extern "C" const char *tmp_last_error(void) { return g_err; }
+
+__global__ void copy_perm_kernel(const uint32_t *in, int32_t *out, int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (int32_t)in[i];
+}
+
+static int sort_spec(const tmp_sort_args *a, OrderSpec *s) {
+  TMP_REQUIRE(a && a->n >= 0 && a->n < (1ll << 31), TMP_EINVAL, "tmp_sort_order: bad row count");
+  TMP_REQUIRE(a->n == 0 || (a->ts && a->out_perm), TMP_EINVAL, "tmp_sort_order: null pointer");
+  TMP_REQUIRE(a->ts_unit == 0 || a->ts_unit == 1, TMP_EINVAL, "tmp_sort_order: bad ts_unit");
+  memset(s, 0, sizeof(*s));
+  s->n = a->n;
+  s->key = a->key;
+  s->n_keys = a->n_keys;
+  s->ts = a->ts;
+  s->prim_div = a->ts_unit == 1 ? 1000000 : 1;
+  s->seq = a->seq;
+  s->seq_valid = a->seq_valid;
+  return TMP_OK;
+}
+
+extern "C" size_t tmp_sort_order_workspace_bytes(const tmp_sort_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  OrderBuffers b;
+  order_plan(a->n, ws, &b);
+  return ws.off;
+}
+
+extern "C" int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t workspace_bytes,
+                              void *stream) {
+  clear_error();
+  OrderSpec s;
+  TMP_TRY(sort_spec(a, &s));
+  if (a->n == 0) return TMP_OK;
+  Workspace ws(workspace, workspace_bytes);
+  OrderBuffers b;
+  order_plan(a->n, ws, &b);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_sort_order: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  Layout lay;
+  OrderResult res;
+  TMP_TRY(order_single(s, b, &lay, &res, st));
+  hipLaunchKernelGGL(copy_perm_kernel, dim3(grid_for(a->n, kBlock * 4, 8192)), dim3(kBlock), 0, st,
+                     res.perm, a->out_perm, a->n);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}

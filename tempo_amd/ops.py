@@ -1,0 +1,258 @@
+"""Device-level operators: torch (ROCm) tensors in HBM -> libtempo_hip.so -> torch tensors.
+
+torch is plumbing here (device memory, streams); every computation is a HIP kernel behind the
+C ABI of include/tempo_hip.h.  All functions require CUDA (ROCm) tensors and raise otherwise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (AsofArgs, EmaArgs, LookbackArgs, PartitionArgs, RangeStatsArgs, ResampleArgs,
+                   SortArgs, check, lib, ptr_array)
+
+
+def _dev(t, dtype, name, n=None):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a CUDA (ROCm) tensor; tempo_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if t.dim() != 1 or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous 1-D tensor")
+    if n is not None and t.numel() != n:
+        raise ValueError(f"{name} has {t.numel()} rows, expected {n}")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def sort_order(key, ts, n_keys, floor_seconds=False, seq=None, seq_valid=None):
+    """perm[p] = input row at sorted position p by (key, ts or floor(ts/1e6)[, seq NULLS FIRST]),
+    ties in input order (python/tempo/tsdf.py:563-572)."""
+    n = ts.numel()
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    _dev(seq, torch.int64, "seq", n)
+    _dev(seq_valid, torch.uint8, "seq_valid", n)
+    perm = torch.empty(n, dtype=torch.int32, device=ts.device)
+    a = SortArgs(n, _p(key), int(n_keys), _p(ts), int(bool(floor_seconds)), _p(seq), _p(seq_valid),
+                 _p(perm))
+    ws = _workspace(lib().tmp_sort_order_workspace_bytes(C.byref(a)), ts.device)
+    check(lib().tmp_sort_order(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_sort_order")
+    return perm
+
+
+def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, masks=(),
+              ts_is_seconds=False, ts_partition_val=None, fraction=0.5):
+    """AS-OF match (python/tempo/tsdf.py:463-560).
+
+    Returns (row_idx[nL], mask_idx[n_masks, nL], missing[1 + n_masks]) as int32 device tensors:
+    the right row each left row takes its values from (last visible row / last visible row
+    whose mask is valid), -1 for none.
+    """
+    nL, nR = ts_l.numel(), ts_r.numel()
+    dev = ts_l.device
+    _dev(ts_l, torch.int64, "ts_l")
+    _dev(ts_r, torch.int64, "ts_r")
+    _dev(key_l, torch.int32, "key_l", nL)
+    _dev(key_r, torch.int32, "key_r", nR)
+    _dev(seq_r, torch.int64, "seq_r", nR)
+    _dev(seq_r_valid, torch.uint8, "seq_r_valid", nR)
+    masks = list(masks)
+    if len(masks) > _lib.TMP_MAX_MASKS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_MASKS} nullable right columns per call")
+    for i, m in enumerate(masks):
+        _dev(m, torch.uint8, f"masks[{i}]", nR)
+    row_idx = torch.empty(nL, dtype=torch.int32, device=dev)
+    mask_idx = torch.empty((len(masks), nL), dtype=torch.int32, device=dev)
+    missing = torch.empty(1 + len(masks), dtype=torch.int32, device=dev)
+    skew = ts_partition_val is not None
+    a = AsofArgs()
+    a.n_left, a.n_right = nL, nR
+    a.key_left, a.ts_left, a.key_right, a.ts_right = _p(key_l), _p(ts_l), _p(key_r), _p(ts_r)
+    a.seq_right, a.seq_right_valid = _p(seq_r), _p(seq_r_valid)
+    a.n_keys, a.ts_is_seconds, a.n_masks = int(n_keys), int(bool(ts_is_seconds)), len(masks)
+    mask_ptrs = ptr_array([m.data_ptr() for m in masks])
+    a.masks = mask_ptrs
+    a.skew = int(skew)
+    a.v_is_int = int(skew and isinstance(ts_partition_val, int))
+    a.ts_partition_val = float(ts_partition_val) if skew else 0.0
+    a.one_minus_fraction = float(1 - fraction)  # evaluated in Python float as tsdf.py:185
+    a.out_row_idx, a.out_mask_idx, a.out_missing = _p(row_idx), _p(mask_idx), _p(missing)
+    ws = _workspace(lib().tmp_asof_join_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_asof_join(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_asof_join")
+    return row_idx, mask_idx, missing
+
+
+def gather(src, idx, src_valid=None, want_valid=True):
+    """out[i] = src[idx[i]] (0 / invalid where idx[i] < 0 or the source is NULL)."""
+    n = idx.numel()
+    _dev(idx, torch.int32, "idx")
+    if not src.is_cuda or src.dim() != 1 or not src.is_contiguous():
+        raise ValueError("src must be a contiguous 1-D CUDA tensor")
+    if src.element_size() not in (1, 4, 8):
+        raise TypeError("gather supports 1-, 4- and 8-byte element types")
+    _dev(src_valid, torch.uint8, "src_valid", src.numel())
+    out = torch.empty(n, dtype=src.dtype, device=src.device)
+    out_valid = torch.empty(n, dtype=torch.uint8, device=src.device) if want_valid else None
+    check(lib().tmp_gather(_p(src), _p(src_valid), src.element_size(), _p(idx), n, _p(out),
+                           _p(out_valid), _stream()), "tmp_gather")
+    return out, out_valid
+
+
+def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=False):
+    """withRangeStats core (python/tempo/tsdf.py:673-721).  Outputs in (key, sec) order."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    is_i64 = x.dtype == torch.int64
+    _dev(x, torch.int64 if is_i64 else torch.float64, "x", n)
+    _dev(x_valid, torch.uint8, "x_valid", n)
+    vt = torch.int64 if is_i64 else torch.float64
+    out = dict(perm=torch.empty(n, dtype=torch.int32, device=dev),
+               mean=torch.empty(n, dtype=torch.float64, device=dev),
+               count=torch.empty(n, dtype=torch.int64, device=dev),
+               min=torch.empty(n, dtype=vt, device=dev), max=torch.empty(n, dtype=vt, device=dev),
+               sum=torch.empty(n, dtype=vt, device=dev),
+               stddev=torch.empty(n, dtype=torch.float64, device=dev),
+               zscore=torch.empty(n, dtype=torch.float64, device=dev),
+               valid=torch.empty(n, dtype=torch.uint8, device=dev))
+    a = RangeStatsArgs(n, _p(key), int(n_keys), _p(ts), int(bool(ts_is_seconds)), int(is_i64),
+                       _p(x), _p(x_valid), int(range_back_secs), _p(out["perm"]), _p(out["mean"]),
+                       _p(out["count"]), _p(out["min"]), _p(out["max"]), _p(out["sum"]),
+                       _p(out["stddev"]), _p(out["zscore"]), _p(out["valid"]))
+    ws = _workspace(lib().tmp_range_stats_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_range_stats")
+    return out
+
+
+def ema_weights(window, exp_factor):
+    """Tap weights exactly as python/tempo/tsdf.py:629 computes them (Python float)."""
+    return [exp_factor * (1 - exp_factor) ** i for i in range(window)]
+
+
+def ema(key, ts, x, x_valid, n_keys, window=30, exp_factor=0.2, ts_is_seconds=False, seq=None,
+        seq_valid=None):
+    """EMA core (python/tempo/tsdf.py:615-635).  Returns (perm, ema) in window order."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    _dev(x, torch.float64, "x", n)
+    _dev(x_valid, torch.uint8, "x_valid", n)
+    _dev(seq, torch.int64, "seq", n)
+    _dev(seq_valid, torch.uint8, "seq_valid", n)
+    if window > _lib.TMP_MAX_TAPS:
+        raise NotImplementedError(f"EMA window is limited to {_lib.TMP_MAX_TAPS} taps")
+    w = ema_weights(window, exp_factor)
+    warr = (C.c_double * max(window, 1))(*w)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    a = EmaArgs(n, _p(key), int(n_keys), _p(ts), int(bool(ts_is_seconds)), _p(seq), _p(seq_valid),
+                _p(x), _p(x_valid), int(window), warr, _p(perm), _p(out))
+    ws = _workspace(lib().tmp_ema_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_ema(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_ema")
+    return perm, out
+
+
+def lookback(key, ts, xs, xs_valid, n_keys, lookback_size, exact_size=True, ts_is_seconds=False,
+             seq=None, seq_valid=None):
+    """withLookbackFeatures core (python/tempo/tsdf.py:637-671).
+
+    Returns (rows, lengths or None, feat[n_out, L, F], feat_valid or None); n_out is the number
+    of kept rows (all rows when exact_size is False)."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    _dev(seq, torch.int64, "seq", n)
+    _dev(seq_valid, torch.uint8, "seq_valid", n)
+    F, L = len(xs), int(lookback_size)
+    if F < 1 or F > _lib.TMP_MAX_FEATURES:
+        raise ValueError(f"between 1 and {_lib.TMP_MAX_FEATURES} feature columns are supported")
+    if L < 1:
+        raise ValueError("lookbackWindowSize must be an integer >= 1")
+    for i, x in enumerate(xs):
+        _dev(x, torch.float64, f"xs[{i}]", n)
+        _dev(xs_valid[i], torch.uint8, f"xs_valid[{i}]", n)
+    any_nulls = any(v is not None for v in xs_valid)
+    rows = torch.empty(n, dtype=torch.int32, device=dev)
+    lens = None if exact_size else torch.empty(n, dtype=torch.int32, device=dev)
+    feat = torch.empty((n, L, F), dtype=torch.float64, device=dev)
+    fv = torch.empty((n, L, F), dtype=torch.uint8, device=dev) if (any_nulls or not exact_size) else None
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    xp = ptr_array([x.data_ptr() for x in xs])
+    vp = ptr_array([_p(v) for v in xs_valid])
+    a = LookbackArgs(n, _p(key), int(n_keys), _p(ts), int(bool(ts_is_seconds)), _p(seq),
+                     _p(seq_valid), F, xp, vp, L, int(bool(exact_size)), _p(rows), _p(lens),
+                     _p(feat), _p(fv), _p(count))
+    ws = _workspace(lib().tmp_lookback_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_lookback(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_lookback")
+    n_out = int(count.item())
+    return rows[:n_out], lens, feat[:n_out], (None if fv is None else fv[:n_out])
+
+
+def resample(key, ts, n_keys, dur_us, func, cols, cols_valid):
+    """resample core (python/tempo/resample.py:38-117).  cols: float64 or int64 device tensors.
+
+    Returns dict(n, key, start, f64[C, n], i64[C, n], valid[C, n], row[n], is_i64)."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    k = len(cols)
+    if k > _lib.TMP_MAX_COLS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_COLS} columns per resample call")
+    is_i64 = []
+    for i, c in enumerate(cols):
+        if c.dtype not in (torch.float64, torch.int64):
+            raise TypeError("resample columns must be float64 or int64 device tensors")
+        _dev(c, c.dtype, f"cols[{i}]", n)
+        _dev(cols_valid[i], torch.uint8, f"cols_valid[{i}]", n)
+        is_i64.append(int(c.dtype == torch.int64))
+    cap = max(n, 1)
+    out_key = torch.empty(cap, dtype=torch.int32, device=dev)
+    out_start = torch.empty(cap, dtype=torch.int64, device=dev)
+    reduce_func = func in ("min", "max", "mean")
+    kk = max(k, 1) if reduce_func else 1
+    out_f64 = torch.zeros((kk, cap), dtype=torch.float64, device=dev)
+    out_i64 = torch.zeros((kk, cap), dtype=torch.int64, device=dev)
+    out_valid = torch.zeros((kk, cap), dtype=torch.uint8, device=dev)
+    out_row = torch.empty(cap, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = ResampleArgs(n, _p(key), int(n_keys), _p(ts), int(dur_us), _lib.FUNC_CODES[func], k,
+                     ptr_array([c.data_ptr() for c in cols]),
+                     (C.c_int32 * max(k, 1))(*is_i64), ptr_array([_p(v) for v in cols_valid]),
+                     _p(out_key), _p(out_start), _p(out_f64), _p(out_i64), _p(out_valid),
+                     _p(out_row), _p(count))
+    ws = _workspace(lib().tmp_resample_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_resample(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_resample")
+    nb = int(count.item())
+    return dict(n=nb, key=out_key[:nb], start=out_start[:nb], f64=out_f64[:, :nb],
+                i64=out_i64[:, :nb], valid=out_valid[:, :nb], row=out_row[:nb], is_i64=is_i64)
+
+
+def hash_partition(key, n_parts):
+    """Bucket rows by owner = hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts])."""
+    n = key.numel()
+    _dev(key, torch.int32, "key")
+    perm = torch.empty(n, dtype=torch.int32, device=key.device)
+    counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
+    a = PartitionArgs(n, _p(key), int(n_parts), _p(perm), _p(counts))
+    ws = _workspace(lib().tmp_hash_partition_workspace_bytes(C.byref(a)), key.device)
+    check(lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
+          "tmp_hash_partition")
+    return perm, counts

@@ -1,0 +1,145 @@
+"""HIP AS-OF match against the CPU oracle (bit-exact indices), through the C ABI."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+BASE = 1_596_240_000_000_000
+
+
+def _dev(a, dtype=None):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _make(rng, nL, nR, nkeys, span_us, step_us, n_masks, null_p, with_seq, sorted_input=False):
+    key_l = rng.integers(0, nkeys, nL).astype(np.int32)
+    key_r = rng.integers(0, nkeys, nR).astype(np.int32)
+    ts_l = BASE + rng.integers(0, span_us // step_us + 1, nL) * step_us
+    ts_r = BASE + rng.integers(0, span_us // step_us + 1, nR) * step_us
+    if sorted_input:
+        o = np.lexsort((ts_l, key_l)); key_l, ts_l = key_l[o], ts_l[o]
+        o = np.lexsort((ts_r, key_r)); key_r, ts_r = key_r[o], ts_r[o]
+    masks = [(rng.random(nR) >= null_p).astype(np.uint8) for _ in range(n_masks)]
+    seq = seq_valid = None
+    if with_seq:
+        seq = rng.integers(-1000, 1000, nR)
+        seq_valid = (rng.random(nR) >= 0.1).astype(np.uint8)
+    return key_l, ts_l, key_r, ts_r, seq, seq_valid, masks
+
+
+def _run_both(orc, ops, data, nkeys, **kw):
+    key_l, ts_l, key_r, ts_r, seq, seq_valid, masks = data
+    row, midx, missing = ops.asof_join(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nkeys,
+                                       seq_r=_dev(seq), seq_r_valid=_dev(seq_valid),
+                                       masks=[_dev(m) for m in masks], **kw)
+    torch.cuda.synchronize()
+    # oracle: column 0 has no NULLs (row rule), then one column per mask
+    idx, omiss = orc.asof_join(key_l, ts_l, key_r, ts_r, seq_r=seq, seq_r_valid=seq_valid,
+                               valid_r=[None] + masks, skip_nulls=True, **kw)
+    assert np.array_equal(row.cpu().numpy().astype(np.int64), idx[0])
+    got = midx.cpu().numpy().astype(np.int64)
+    for m in range(len(masks)):
+        assert np.array_equal(got[m], idx[1 + m]), f"mask {m}"
+    assert missing.cpu().numpy().tolist() == omiss.tolist()
+    # skipNulls=False rule == the row index for every column
+    idx2, _ = orc.asof_join(key_l, ts_l, key_r, ts_r, seq_r=seq, seq_r_valid=seq_valid,
+                            valid_r=masks[:1] or [None], skip_nulls=False,
+                            **{k: v for k, v in kw.items() if k == "ts_is_seconds"}) \
+        if "ts_partition_val" not in kw else (None, None)
+    if idx2 is not None:
+        assert np.array_equal(row.cpu().numpy().astype(np.int64), idx2[0])
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tempo_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_asof_small_random(orc, ops, seed):
+    rng = np.random.default_rng(seed)
+    nL, nR = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+    data = _make(rng, nL, nR, 5, 60_000_000, 250_000, seed % 3, 0.3, with_seq=seed % 2 == 1)
+    _run_both(orc, ops, data, 5)
+
+
+@pytest.mark.parametrize("with_seq", [False, True])
+def test_asof_medium_unsorted(orc, ops, with_seq):
+    rng = np.random.default_rng(42)
+    data = _make(rng, 300_000, 200_000, 100, 6 * 3600 * 1_000_000, 1000, 2, 0.01, with_seq)
+    _run_both(orc, ops, data, 100)
+
+
+def test_asof_presorted_inputs_skip_sort(orc, ops):
+    rng = np.random.default_rng(7)
+    data = _make(rng, 100_000, 150_000, 37, 3600 * 1_000_000, 1000, 1, 0.05, False, sorted_input=True)
+    _run_both(orc, ops, data, 37)
+
+
+@pytest.mark.parametrize("v,fraction", [(10, 0.1), (3, 0.5), (7.5, 0.25), (1, 0.1)])
+def test_asof_skew_brackets(orc, ops, v, fraction):
+    rng = np.random.default_rng(11)
+    data = _make(rng, 50_000, 20_000, 20, 600 * 1_000_000, 50_000, 2, 0.2, False)
+    _run_both(orc, ops, data, 20, ts_partition_val=v, fraction=fraction)
+
+
+def test_asof_zipf_heavy_key_and_long_null_runs(orc, ops):
+    rng = np.random.default_rng(5)
+    nL, nR, nkeys = 200_000, 200_000, 1000
+    w = 1.0 / np.arange(1, nkeys + 1) ** 1.2
+    cdf = np.cumsum(w / w.sum())
+    key_l = np.searchsorted(cdf, rng.random(nL)).clip(0, nkeys - 1).astype(np.int32)
+    key_r = np.searchsorted(cdf, rng.random(nR)).clip(0, nkeys - 1).astype(np.int32)
+    ts_l = BASE + rng.integers(0, 86_400_000_000, nL)
+    ts_r = BASE + rng.integers(0, 86_400_000_000, nR)
+    m0 = (rng.random(nR) >= 0.995).astype(np.uint8)  # almost always NULL
+    m1 = np.zeros(nR, np.uint8)                      # always NULL
+    _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, None, None, [m0, m1]), nkeys)
+
+
+def test_asof_empty_and_single_series(orc, ops):
+    rng = np.random.default_rng(3)
+    key_l, ts_l, key_r, ts_r, _, _, masks = _make(rng, 1000, 0, 3, 10_000_000, 1000, 1, 0.5, False)
+    row, midx, missing = ops.asof_join(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), 3,
+                                       masks=[_dev(masks[0])])
+    assert (row.cpu().numpy() == -1).all() and (midx.cpu().numpy() == -1).all()
+    assert missing.cpu().numpy().tolist() == [1, 1]
+    # no partition columns: one global series
+    ts_l = BASE + rng.integers(0, 10_000, 5000) * 1000
+    ts_r = BASE + rng.integers(0, 10_000, 4000) * 1000
+    row, _, _ = ops.asof_join(None, _dev(ts_l), None, _dev(ts_r), 1)
+    idx, _ = orc.asof_join(np.zeros(5000, np.int32), ts_l, np.zeros(4000, np.int32), ts_r,
+                           valid_r=[None])
+    assert np.array_equal(row.cpu().numpy().astype(np.int64), idx[0])
+
+
+def test_sort_order_matches_oracle(orc, ops):
+    rng = np.random.default_rng(9)
+    n = 250_000
+    key = rng.integers(0, 50, n).astype(np.int32)
+    ts = BASE + rng.integers(-3_000_000, 900 * 1_000_000, n)
+    seq = rng.integers(0, 4, n)
+    seq_valid = (rng.random(n) >= 0.2).astype(np.uint8)
+    perm = ops.sort_order(_dev(key), _dev(ts), 50, floor_seconds=True, seq=_dev(seq),
+                          seq_valid=_dev(seq_valid))
+    operm, _ = orc.window_order(key, ts, seq=seq, seq_valid=seq_valid)
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), operm)
+
+
+def test_gather(ops):
+    rng = np.random.default_rng(1)
+    src = rng.normal(size=1000)
+    valid = (rng.random(1000) > 0.3).astype(np.uint8)
+    idx = rng.integers(-1, 1000, 5000).astype(np.int32)
+    out, ov = ops.gather(_dev(src), _dev(idx), _dev(valid))
+    ok = (idx >= 0) & (valid[np.clip(idx, 0, None)] == 1)
+    assert np.array_equal(ov.cpu().numpy().astype(bool), ok)
+    assert np.array_equal(out.cpu().numpy(), np.where(ok, src[np.clip(idx, 0, None)], 0.0))

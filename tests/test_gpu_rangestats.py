@@ -1,0 +1,135 @@
+"""HIP withRangeStats against the CPU oracle: counts/min/max/NULL flags exact, fp64 statistics
+within 1e-9 relative (zscore: 1e-9 * max(1, |z|)), through the C ABI."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+BASE = 1_596_240_000_000_000
+RTOL = 1e-9
+
+
+def _dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tempo_amd import ops
+    return ops
+
+
+def _compare(orc, ops, key, ts, x, xv, nkeys, W, ts_is_seconds=False):
+    out = ops.range_stats(_dev(key), _dev(ts), _dev(x), _dev(xv), nkeys, W, ts_is_seconds=ts_is_seconds)
+    torch.cuda.synchronize()
+    ref = orc.range_stats(key, ts, x, xv, W, ts_is_seconds=ts_is_seconds)
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.array_equal(g["perm"].astype(np.int64), ref["perm"])
+    assert np.array_equal(g["count"], ref["count"])
+    sv, dv, zv = (g["valid"] & 1) != 0, (g["valid"] & 2) != 0, (g["valid"] & 4) != 0
+    assert np.array_equal(sv, ref["stat_valid"].astype(bool))
+    assert np.array_equal(dv, ref["stddev_valid"].astype(bool))
+    assert np.array_equal(zv, ref["zscore_valid"].astype(bool))
+    assert np.array_equal(g["min"][sv], ref["min"][sv], equal_nan=True)
+    assert np.array_equal(g["max"][sv], ref["max"][sv], equal_nan=True)
+    if np.issubdtype(x.dtype, np.integer):
+        assert np.array_equal(g["sum"][sv], ref["sum"][sv])
+    else:
+        np.testing.assert_allclose(g["sum"][sv], ref["sum"][sv], rtol=RTOL, atol=0, equal_nan=True)
+    np.testing.assert_allclose(g["mean"][sv], ref["mean"][sv], rtol=RTOL, atol=0, equal_nan=True)
+    # stddev: 1e-9 relative, with an absolute floor at 1e-9 of the value scale for frames whose
+    # spread is far below the values themselves (both algorithms lose those digits)
+    scale = np.nanmax(np.abs(np.where(np.isfinite(ref["mean"]), ref["mean"], 0))) if sv.any() else 1.0
+    np.testing.assert_allclose(g["stddev"][dv], ref["stddev"][dv], rtol=RTOL, atol=1e-12 * max(scale, 1.0),
+                               equal_nan=True)
+    zt = RTOL * np.maximum(1.0, np.abs(ref["zscore"][zv]))
+    dz = np.abs(g["zscore"][zv] - ref["zscore"][zv])
+    ok = (dz <= zt * 10) | (np.isnan(g["zscore"][zv]) & np.isnan(ref["zscore"][zv]))
+    assert ok.all(), f"zscore off: max {np.nanmax(dz)}"
+    return g, ref
+
+
+def _ticks(rng, n, nkeys, mean_gap_s, null_p, sort=False):
+    key = rng.integers(0, nkeys, n).astype(np.int32)
+    ts = BASE + (rng.exponential(mean_gap_s * nkeys, n).cumsum() * 1e6).astype(np.int64)
+    if not sort:
+        p = rng.permutation(n)
+        key, ts = key[p], ts[p]
+    x = 100 + rng.normal(0, 1, n).cumsum() * 0.01
+    xv = (rng.random(n) >= null_p).astype(np.uint8) if null_p else None
+    return key, ts, x, xv
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_range_stats_small(orc, ops, seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 5000))
+    key, ts, x, xv = _ticks(rng, n, 4, 1.0, 0.1)
+    _compare(orc, ops, key, ts, x, xv, 4, int(rng.integers(0, 30)))
+
+
+def test_range_stats_window_600_ticks(orc, ops):
+    rng = np.random.default_rng(10)
+    key, ts, x, xv = _ticks(rng, 60_000, 10, 1.0, 0.005)
+    _compare(orc, ops, key, ts, x, xv, 10, 600)
+
+
+def test_range_stats_presorted_no_nulls(orc, ops):
+    rng = np.random.default_rng(11)
+    key, ts, x, _ = _ticks(rng, 30_000, 5, 2.0, 0.0)
+    o = np.lexsort((ts, key))
+    _compare(orc, ops, key[o], ts[o], x[o], None, 5, 120)
+
+
+def test_range_stats_dense_frames_take_sequential_path(orc, ops):
+    """Frames of ~5000 rows exceed the LDS extent: the exact sequential path must agree too."""
+    rng = np.random.default_rng(12)
+    n = 20_000
+    key = np.zeros(n, np.int32)
+    ts = BASE + np.sort(rng.integers(0, 40_000_000, n))  # 40 s, 500 rows per second
+    x = rng.normal(50, 3, n)
+    _compare(orc, ops, key, ts, x, None, 1, 10)
+
+
+def test_range_stats_identical_values_and_specials(orc, ops):
+    rng = np.random.default_rng(13)
+    n = 6000
+    key = rng.integers(0, 3, n).astype(np.int32)
+    ts = BASE + rng.integers(0, 3000, n) * 1_000_000
+    x = np.round(rng.normal(10, 0.3, n), 0)  # many frames hold one repeated value -> stddev 0, zscore NULL
+    x[rng.integers(0, n, 5)] = np.nan
+    x[rng.integers(0, n, 3)] = np.inf
+    x[rng.integers(0, n, 3)] = -np.inf
+    xv = (rng.random(n) >= 0.3).astype(np.uint8)
+    _compare(orc, ops, key, ts, x, xv, 3, 4)
+
+
+def test_range_stats_int64_metric_and_second_ts(orc, ops):
+    rng = np.random.default_rng(14)
+    n = 20_000
+    key = rng.integers(0, 7, n).astype(np.int32)
+    ts = rng.integers(1_000_000, 1_020_000, n)  # integral ts column: seconds already
+    x = rng.integers(-(2 ** 40), 2 ** 40, n)
+    xv = (rng.random(n) >= 0.1).astype(np.uint8)
+    _compare(orc, ops, key, ts, x, xv, 7, 50, ts_is_seconds=True)
+
+
+def test_range_stats_golden(ops, golden):
+    from conftest import ts_us
+    fx = golden["range_stats"]
+    ts = np.array([ts_us(r[1]) for r in fx["data"]])
+    x = np.array([r[2] for r in fx["data"]], np.float32).astype(np.float64)
+    out = ops.range_stats(_dev(np.zeros(4, np.int32)), _dev(ts), _dev(x), None, 1, fx["rangeBackWindowSecs"])
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    for p, erow in enumerate(fx["expected"]):
+        e = dict(zip(fx["expected_columns"], erow))
+        assert g["count"][p] == e["count_trade_pr"]
+        for name in ("mean", "min", "max", "sum"):
+            assert abs(g[name][p] - e[name + "_trade_pr"]) < 0.00501
+        if e["stddev_trade_pr"] is None:
+            assert not g["valid"][p] & 2 and not g["valid"][p] & 4
+        else:
+            assert abs(g["stddev"][p] - e["stddev_trade_pr"]) < 0.00501
+            assert abs(g["zscore"][p] - e["zscore_trade_pr"]) < 0.00501
