@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AS-OF join + withRangeStats rows/sec at 1B rows on MI355X.
+
+One step = one pass of the hot path over one batch of device-resident synthetic input:
+  1. asofJoin of `rows/2` trades against `rows/2` quotes (10 000 Zipf(1.2) symbols, uniform
+     microsecond timestamps over one trading day, skew mode tsPartitionVal=10 fraction=0.1,
+     three joined right columns, two of them with 1 % NULLs), including the gather that
+     materialises the joined columns;
+  2. withRangeStats(rangeBackWindowSecs=600) of one fp64 metric over `rows` ticks
+     (100 symbols, Exp(1 s) inter-arrival per symbol, 0.5 % NULLs).
+value = rows consumed by both operators (2 x rows) / step time, inputs already in HBM.
+With --gpus N (one process per GPU, launched by torch.distributed.run) every rank generates
+its own `rows` (weak scaling); the step then starts with the key shuffle (device bucketing by
+owner(key) + RCCL all-to-all) and the operators run on the series each rank owns.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tempo_amd import _lib, ops  # noqa: E402
+
+BASE_US = 1_596_240_000_000_000  # 2020-08-01 00:00:00 UTC
+DAY_US = 86_400_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def gen_trades_quotes(dev, n_left, n_right, n_keys, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w = 1.0 / torch.arange(1, n_keys + 1, dtype=torch.float64, device=dev) ** 1.2
+    cdf = torch.cumsum(w / w.sum(), 0)
+
+    def zipf(n):
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        step = 1 << 26
+        for s in range(0, n, step):
+            m = min(step, n - s)
+            u = torch.rand(m, generator=g, device=dev, dtype=torch.float64)
+            out[s:s + m] = torch.searchsorted(cdf, u).clamp_(max=n_keys - 1).to(torch.int32)
+        return out
+
+    d = {}
+    d["key_l"] = zipf(n_left)
+    d["ts_l"] = BASE_US + torch.randint(0, DAY_US, (n_left,), generator=g, device=dev, dtype=torch.int64)
+    d["key_r"] = zipf(n_right)
+    d["ts_r"] = BASE_US + torch.randint(0, DAY_US, (n_right,), generator=g, device=dev, dtype=torch.int64)
+    d["bid"] = 100.0 + torch.randn(n_right, generator=g, device=dev, dtype=torch.float64)
+    d["ask"] = d["bid"] + 0.05
+    d["bid_valid"] = (torch.rand(n_right, generator=g, device=dev) >= 0.01).to(torch.uint8)
+    d["ask_valid"] = (torch.rand(n_right, generator=g, device=dev) >= 0.01).to(torch.uint8)
+    return d
+
+
+def gen_ticks(dev, n, n_keys, seed, key_offset=0):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    d = {}
+    d["key"] = torch.randint(0, n_keys, (n,), generator=g, device=dev, dtype=torch.int32)
+    gaps = torch.empty(n, dtype=torch.float64, device=dev).exponential_(float(n_keys), generator=g)
+    d["ts"] = BASE_US + (torch.cumsum(gaps, 0) * 1e6).to(torch.int64)
+    del gaps
+    steps = torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+    d["x"] = 100.0 + torch.cumsum(steps, 0) * 0.01
+    del steps
+    d["x_valid"] = (torch.rand(n, generator=g, device=dev) >= 0.005).to(torch.uint8)
+    return d
+
+
+# algorithmic bytes one launch of a kernel moves, per row it processes (every input read once,
+# every output written once)
+KERNEL_BYTES_PER_ROW = {
+    "radix_scatter_kernel": 24.0,     # (8 B sort word + 4 B row id) in and out
+    "radix_hist_kernel": 8.0,         # sort word in
+    "range_stats_kernel<T>": 81.0,    # word 8 + metric 8 + row id 4 in; 7 stats x 8 + perm 4 + flags 1 out
+    "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out
+    "gather_sorted_kernel<T>": 20.0,  # perm 4 + value 8 in, value 8 out
+    "asof_merge_kernel": 44.0,        # per left row: word 8 + perm 4 in, right word 8 + perm 4 + 2x lastnn 4 in, 3 idx out
+    "lastnn_scan_kernel": 16.0,       # word 8 in, 2 x 4 B out
+    "lastnn_reduce_kernel": 8.0,
+    "range_scan_kernel": 12.0,        # key 4 + ts 8 in
+    "make_comp_kernel": 24.0,         # key 4 + ts 8 in, word 8 + id 4 out (+ mask bytes on the right side)
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per operator per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from tempo_amd.dist import shuffle_by_key
+
+    rows = args.rows
+    n_left = n_right = rows // 2
+    ASOF_KEYS, TICK_KEYS = 10_000, 100
+    tq = gen_trades_quotes(dev, n_left, n_right, ASOF_KEYS, 4567 + rank)
+    tk = gen_ticks(dev, rows, TICK_KEYS, 2345 + rank)
+    torch.cuda.synchronize()
+
+    profiling = not args.no_profile
+    if profiling:
+        _lib.profile_enable(True)
+
+    def step():
+        q = tq
+        t = tk
+        if world > 1:
+            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column
+            _lib.profile_tag(0)
+            kl, (tl,), _, _ = shuffle_by_key(tq["key_l"], [tq["ts_l"]])
+            kr, (tr, bid, ask, bv, av), _, _ = shuffle_by_key(
+                tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]])
+            q = dict(key_l=kl, ts_l=tl, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
+            kk, (tt, xx, xv), _, _ = shuffle_by_key(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
+            t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
+        _lib.profile_tag(1)
+        row, midx, missing = ops.asof_join(q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS,
+                                           masks=[q["bid_valid"], q["ask_valid"]],
+                                           ts_partition_val=10, fraction=0.1)
+        r_ts, _ = ops.gather(q["ts_r"], row)
+        r_bid, _ = ops.gather(q["bid"], midx[0])
+        r_ask, _ = ops.gather(q["ask"], midx[1])
+        n1 = q["ts_l"].numel() + q["ts_r"].numel()
+        del row, midx, r_ts, r_bid, r_ask
+        _lib.profile_tag(2)
+        out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
+        n2 = t["ts"].numel()
+        del out
+        return n1, n2
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows_done = 0
+    for _ in range(args.steps):
+        n1, n2 = step()
+        rows_done += n1 + n2
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rows_done], dtype=torch.int64, device=dev)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rows_done = int(r.item())
+
+    # ---- per-kernel device time from the HIP events recorded on the launch stream
+    roofline = None
+    kernels = {}
+    op_ms = {1: 0.0, 2: 0.0, 0: 0.0}
+    if profiling:
+        rows_of = {1: None, 2: None}
+        for name, tag, ms in _lib.profile_read():
+            k = kernels.setdefault(name, dict(launches=0, ms=0.0, rows=0.0))
+            k["launches"] += 1
+            k["ms"] += ms
+            op_ms[tag] = op_ms.get(tag, 0.0) + ms
+            # rows one launch covers: the asof launches alternate left/right (rows/2 each), the
+            # range-stats launches cover `rows` (single-GPU layout; per-rank counts differ by
+            # the key hash under --gpus N and are close to these)
+            k["rows"] += (rows / 2 if tag == 1 else rows)
+        dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        name, k = dom
+        bpr = KERNEL_BYTES_PER_ROW.get(name)
+        if bpr is not None:
+            gbs = k["rows"] * bpr / (k["ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=name, achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                            launches=k["launches"], avg_launch_ms=round(k["ms"] / k["launches"], 4),
+                            bytes_per_row=bpr)
+        else:
+            roofline = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=None, traffic=None)
+
+    # ---- CPU baseline: the C oracle (a port of the reference plan) on a bounded sample, 1 core
+    cpu = None
+    if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
+        cpu = cpu_baseline(args.cpu_sample)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rows_done / elapsed
+        top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        line = {
+            "metric": "AS-OF join + withRangeStats rows/sec at 1B rows (1-8 GPU); % HBM peak",
+            "value": value, "unit": "rows/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int64 keys/timestamps + f64 metrics",
+            "data": "synthetic",
+            "config": {
+                "workload": ("asofJoin %d trades x %d quotes per GPU (10k Zipf(1.2) symbols, "
+                             "tsPartitionVal=10, fraction=0.1, 3 joined cols) + "
+                             "withRangeStats(600 s) on %d ticks per GPU (100 symbols)"
+                             % (n_left, n_right, rows)),
+                "rows_per_gpu_per_op": rows,
+                "parallelism": "key-hash shard x%d" % args.gpus,
+                "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
+                "range_stats_device_ms_per_step": round(op_ms.get(2, 0.0) / args.steps, 3),
+                "shuffle_device_ms_per_step": round(op_ms.get(0, 0.0) / args.steps, 3),
+                "top_kernels_ms_per_step": {n: round(k["ms"] / args.steps, 3) for n, k in top},
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sample_rows):
+    """Time the CPU oracle on host cores over a scaled-down copy of the same workload."""
+    import numpy as np
+
+    from oracle import oracle
+
+    rng = np.random.default_rng(99)
+    nl = nr = sample_rows // 2
+    nk = 10_000
+    w = 1.0 / np.arange(1, nk + 1) ** 1.2
+    cdf = np.cumsum(w / w.sum())
+    key_l = np.searchsorted(cdf, rng.random(nl)).clip(0, nk - 1).astype(np.int32)
+    key_r = np.searchsorted(cdf, rng.random(nr)).clip(0, nk - 1).astype(np.int32)
+    ts_l = BASE_US + rng.integers(0, DAY_US, nl)
+    ts_r = BASE_US + rng.integers(0, DAY_US, nr)
+    vb = (rng.random(nr) >= 0.01).astype(np.uint8)
+    va = (rng.random(nr) >= 0.01).astype(np.uint8)
+    key = rng.integers(0, 100, sample_rows).astype(np.int32)
+    ts = BASE_US + (np.cumsum(rng.exponential(0.01, sample_rows)) * 1e6).astype(np.int64)
+    x = 100 + np.cumsum(rng.normal(0, 1, sample_rows)) * 0.01
+    xv = (rng.random(sample_rows) >= 0.005).astype(np.uint8)
+    oracle.lib()
+    t0 = time.perf_counter()
+    oracle.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None, vb, va], ts_partition_val=10, fraction=0.1)
+    t1 = time.perf_counter()
+    oracle.range_stats(key, ts, x, xv, 600)
+    t2 = time.perf_counter()
+    total = t2 - t0
+    return dict(value=(nl + nr + sample_rows) / total, unit="rows/s", cores=1, kind="port",
+                sample=("C oracle (oracle/tempo_oracle.c), 1 thread: asofJoin %d+%d rows %.2f s, "
+                        "withRangeStats %d rows %.2f s; same distributions as the GPU workload"
+                        % (nl, nr, t1 - t0, sample_rows, t2 - t1)))
+
+
+if __name__ == "__main__":
+    main()

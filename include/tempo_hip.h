@@ -299,6 +299,21 @@ int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t work
 /* The owner function itself (host-callable, same arithmetic as the kernel). */
 int32_t tmp_key_owner(int32_t key, int32_t n_parts);
 
+/* ---------------------------------------------------------------------------------------
+ * Diagnostics: per-kernel device time (no counterpart in the reference; Spark exposes stage
+ * timings through its UI).  While enabled, every kernel launch of the entry points above is
+ * bracketed by two HIP events on its launch stream.  tmp_profile_enable(1) creates the event
+ * pool the first time (the only call here that creates HIP objects); tmp_profile_get needs the
+ * stream to have been synchronised.  Not thread-safe; at most 8192 launches between resets.
+ */
+int tmp_profile_enable(int on);
+int tmp_profile_reset(void);
+int tmp_profile_count(void);
+int tmp_profile_get(int i, const char **kernel_name, float *ms);
+/* A caller-chosen tag stamped on every launch recorded from now on (e.g. which call it belongs to). */
+int tmp_profile_set_tag(int tag);
+int tmp_profile_tag(int i);
+
 #ifdef __cplusplus
 }
 #endif

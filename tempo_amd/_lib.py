@@ -92,6 +92,12 @@ SYMBOLS = {
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),
+    "tmp_profile_enable": (C.c_int, [C.c_int]),
+    "tmp_profile_reset": (C.c_int, []),
+    "tmp_profile_count": (C.c_int, []),
+    "tmp_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
+    "tmp_profile_set_tag": (C.c_int, [C.c_int]),
+    "tmp_profile_tag": (C.c_int, [C.c_int]),
 }
 
 _LIB = None
@@ -109,6 +115,9 @@ def lib():
             raise TempoHipError(
                 f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                 "(hipcc, gfx950). tempo_amd has no CPU fallback.")
+        # torch must be loaded first: the library has to bind to the HIP runtime torch already
+        # brought into the process, or device pointers and streams would belong to another one.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the build lacks a declared symbol
@@ -135,3 +144,26 @@ def ptr_array(ptrs):
     for i, p in enumerate(ptrs):
         arr[i] = p
     return arr
+
+
+def profile_enable(on=True):
+    check(lib().tmp_profile_enable(int(on)), "tmp_profile_enable")
+
+
+def profile_reset():
+    lib().tmp_profile_reset()
+
+
+def profile_tag(tag):
+    lib().tmp_profile_set_tag(int(tag))
+
+
+def profile_read():
+    """[(kernel name, tag, ms), ...] for every launch since the last reset, in launch order
+    (the stream must have been synchronised)."""
+    out = []
+    name, ms = C.c_char_p(), C.c_float()
+    for i in range(lib().tmp_profile_count()):
+        check(lib().tmp_profile_get(i, C.byref(name), C.byref(ms)), "tmp_profile_get")
+        out.append((name.value.decode(), lib().tmp_profile_tag(i), ms.value))
+    return out

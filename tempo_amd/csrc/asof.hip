@@ -317,11 +317,11 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   if (a->n_right == 0) {  // nothing to match: every index is -1, everything is missing
     int grid = grid_for(a->n_left, kBlock * 4, 8192);
     if (a->out_row_idx)
-      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(kBlock), 0, st, a->out_row_idx, a->n_left, -1);
+      TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_row_idx, a->n_left, -1);
     if (a->n_masks)
-      hipLaunchKernelGGL(fill_i32_kernel, dim3(grid), dim3(kBlock), 0, st, a->out_mask_idx,
+      TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_mask_idx,
                          a->n_left * a->n_masks, -1);
-    hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, a->out_missing, 1 + a->n_masks, 1);
+    TMP_LAUNCH(fill_i32_kernel, dim3(1), dim3(64), st, a->out_missing, 1 + a->n_masks, 1);
     TMP_CHECK_HIP(hipGetLastError());
     return TMP_OK;
   }
@@ -353,10 +353,10 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   if (a->n_masks > 0) {
     ScanGeom g = scan_geom(a->n_right);
     int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
-    hipLaunchKernelGGL(lastnn_reduce_kernel, dim3(blocks), dim3(kUnitBlock), 0, st, ro.comp,
+    TMP_LAUNCH(lastnn_reduce_kernel, dim3(blocks), dim3(kUnitBlock), st, ro.comp,
                        a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg);
-    hipLaunchKernelGGL(lastnn_carry_kernel, dim3(a->n_masks), dim3(1024), 0, st, p.unit_agg, g.units);
-    hipLaunchKernelGGL(lastnn_scan_kernel, dim3(blocks), dim3(kUnitBlock), 0, st, ro.comp,
+    TMP_LAUNCH(lastnn_carry_kernel, dim3(a->n_masks), dim3(1024), st, p.unit_agg, g.units);
+    TMP_LAUNCH(lastnn_scan_kernel, dim3(blocks), dim3(kUnitBlock), st, ro.comp,
                        a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg, p.lastnn);
   }
   SkewParams sp;
@@ -366,7 +366,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   sp.v = a->ts_partition_val;
   sp.one_minus_fraction = a->one_minus_fraction;
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
-  hipLaunchKernelGGL(asof_merge_kernel, dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+  TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
                      ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_row_idx,
                      a->out_mask_idx, a->out_missing);
   TMP_CHECK_HIP(hipGetLastError());

@@ -139,6 +139,21 @@ __device__ __forceinline__ int64_t floordiv_i64(int64_t a, int64_t b) {
   return q;
 }
 
+// Optional per-kernel timing (tmp_profile_* in tempo_hip.h): a pair of HIP events around every
+// launch, recorded on the launch stream.  Off by default; costs nothing when off.
+struct ProfScope {
+  int slot;
+  hipStream_t st;
+  ProfScope(const char *name, hipStream_t s);
+  ~ProfScope();
+};
+
+#define TMP_LAUNCH(kernel, grid, block, st, ...)                       \
+  do {                                                                 \
+    ::tmp::ProfScope prof_scope_(#kernel, st);                         \
+    hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);       \
+  } while (0)
+
 constexpr int kBlock = 256;
 inline int grid_for(int64_t n, int per_block, int max_grid = 1 << 20) {
   int64_t g = (n + per_block - 1) / per_block;

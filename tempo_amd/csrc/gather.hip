@@ -34,15 +34,15 @@ extern "C" int tmp_gather(const void *src, const uint8_t *src_valid, int32_t ele
   int grid = grid_for(n, kBlock * 4, 16384);
   switch (elem_bytes) {
     case 1:
-      hipLaunchKernelGGL(gather_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, st, (const uint8_t *)src,
+      TMP_LAUNCH(gather_kernel<uint8_t>, dim3(grid), dim3(kBlock), st, (const uint8_t *)src,
                          src_valid, idx, n, (uint8_t *)out, out_valid);
       break;
     case 4:
-      hipLaunchKernelGGL(gather_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, st, (const uint32_t *)src,
+      TMP_LAUNCH(gather_kernel<uint32_t>, dim3(grid), dim3(kBlock), st, (const uint32_t *)src,
                          src_valid, idx, n, (uint32_t *)out, out_valid);
       break;
     case 8:
-      hipLaunchKernelGGL(gather_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, st, (const uint64_t *)src,
+      TMP_LAUNCH(gather_kernel<uint64_t>, dim3(grid), dim3(kBlock), st, (const uint64_t *)src,
                          src_valid, idx, n, (uint64_t *)out, out_valid);
       break;
     default:

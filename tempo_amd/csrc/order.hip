@@ -17,6 +17,26 @@ void set_error(const char *fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
+// ---- per-kernel event timing (diagnostic; not thread-safe, one device at a time)
+constexpr int kProfSlots = 8192;
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t *g_prof_ev = nullptr;  // 2 * kProfSlots events, created on first enable
+static const char *g_prof_name[kProfSlots];
+static int g_prof_tag[kProfSlots];
+static int g_prof_cur_tag = 0;
+
+ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), st(s) {
+  if (!g_prof_on || g_prof_n >= kProfSlots) return;
+  slot = g_prof_n++;
+  g_prof_name[slot] = name;
+  g_prof_tag[slot] = g_prof_cur_tag;
+  (void)hipEventRecord(g_prof_ev[2 * slot], st);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof_ev[2 * slot + 1], st);
+}
+
 // ------------------------------------------------------------------------------------------
 // Pass 0: value ranges + "already in order" test, one streaming read of key/ts/seq.
 // ------------------------------------------------------------------------------------------
@@ -316,10 +336,10 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
 }
 
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
-  hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(1), 0, st, b.range);
+  TMP_LAUNCH(range_init_kernel, dim3(1), dim3(1), st, b.range);
   if (s.n > 0) {
     int grid = grid_for(s.n, kBlock * 8, 4096);
-    hipLaunchKernelGGL(range_scan_kernel, dim3(grid), dim3(kBlock), 0, st, s.n, s.key, s.ts,
+    TMP_LAUNCH(range_scan_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts,
                        s.prim_div, s.seq, s.seq_valid, b.range);
   }
   TMP_CHECK_HIP(hipGetLastError());
@@ -359,6 +379,27 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
   return TMP_OK;
 }
 
+// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].
+int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                       hipStream_t st) {
+  SortGeom g = sort_geom(n);
+  int cur = 0;
+  for (int lo = lo_bit; lo < hi_bit; lo += 8) {
+    int nbits = hi_bit - lo < 8 ? hi_bit - lo : 8;
+    uint32_t mask = (1u << nbits) - 1;
+    TMP_LAUNCH(radix_hist_kernel, dim3(g.grid), dim3(RS_THREADS), st, b.comp[cur], n, lo, mask,
+               g.tiles_per_block, b.counts);
+    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
+    TMP_LAUNCH(radix_scatter_kernel, dim3(g.grid), dim3(RS_THREADS), st, b.comp[cur], b.idx[cur],
+               b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits, g.tiles_per_block, b.counts);
+    cur ^= 1;
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  res->comp = b.comp[cur];
+  res->perm = b.idx[cur];
+  return TMP_OK;
+}
+
 int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st) {
   res->comp = b.comp[0];
@@ -367,28 +408,11 @@ int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, Orde
   MaskPtrs mp;
   for (int m = 0; m < TMP_MAX_MASKS; ++m) mp.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
   int grid = grid_for(s.n, kBlock * 4, 8192);
-  hipLaunchKernelGGL(make_comp_kernel, dim3(grid), dim3(kBlock), 0, st, s.n, s.key, s.ts, s.seq,
+  TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts, s.seq,
                      s.seq_valid, lay, s.n_masks, mp, b.comp[0], b.idx[0]);
   TMP_CHECK_HIP(hipGetLastError());
   if (already_sorted) return TMP_OK;
-  SortGeom g = sort_geom(s.n);
-  int cur = 0;
-  for (int lo = lay.low_bits; lo < lay.total_bits(); lo += 8) {
-    int nbits = lay.total_bits() - lo < 8 ? lay.total_bits() - lo : 8;
-    uint32_t mask = (1u << nbits) - 1;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(g.grid), dim3(RS_THREADS), 0, st, b.comp[cur], s.n,
-                       lo, mask, g.tiles_per_block, b.counts);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, b.counts,
-                       RS_RADIX * g.grid);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(g.grid), dim3(RS_THREADS), 0, st, b.comp[cur],
-                       b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], s.n, lo, mask, nbits,
-                       g.tiles_per_block, b.counts);
-    cur ^= 1;
-  }
-  TMP_CHECK_HIP(hipGetLastError());
-  res->comp = b.comp[cur];
-  res->perm = b.idx[cur];
-  return TMP_OK;
+  return order_radix_passes(b, s.n, lay.low_bits, lay.total_bits(), res, st);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
@@ -403,6 +427,27 @@ int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *
 }  // namespace tmp
 
 using namespace tmp;
+
+extern "C" int tmp_profile_enable(int on) {
+  clear_error();
+  if (on && !g_prof_ev) {
+    g_prof_ev = new hipEvent_t[2 * kProfSlots];
+    for (int i = 0; i < 2 * kProfSlots; ++i) TMP_CHECK_HIP(hipEventCreate(&g_prof_ev[i]));
+  }
+  g_prof_on = on != 0;
+  return TMP_OK;
+}
+extern "C" int tmp_profile_reset(void) { g_prof_n = 0; return TMP_OK; }
+extern "C" int tmp_profile_count(void) { return g_prof_n; }
+extern "C" int tmp_profile_set_tag(int tag) { g_prof_cur_tag = tag; return TMP_OK; }
+extern "C" int tmp_profile_tag(int i) { return (i >= 0 && i < g_prof_n) ? g_prof_tag[i] : -1; }
+extern "C" int tmp_profile_get(int i, const char **name, float *ms) {
+  clear_error();
+  TMP_REQUIRE(i >= 0 && i < g_prof_n && name && ms, TMP_EINVAL, "tmp_profile_get: bad index");
+  *name = g_prof_name[i];
+  TMP_CHECK_HIP(hipEventElapsedTime(ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+  return TMP_OK;
+}
 
 extern "C" int tmp_abi_version(void) { return TMP_ABI_VERSION; }
 extern "C" const char *tmp_last_error(void) { return g_err; }
@@ -450,7 +495,7 @@ extern "C" int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t wo
   Layout lay;
   OrderResult res;
   TMP_TRY(order_single(s, b, &lay, &res, st));
-  hipLaunchKernelGGL(copy_perm_kernel, dim3(grid_for(a->n, kBlock * 4, 8192)), dim3(kBlock), 0, st,
+  TMP_LAUNCH(copy_perm_kernel, dim3(grid_for(a->n, kBlock * 4, 8192)), dim3(kBlock), st,
                      res.perm, a->out_perm, a->n);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

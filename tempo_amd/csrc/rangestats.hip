@@ -416,8 +416,7 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   TMP_TRY(order_build(s, lay, sorted, p.ob, &res, st));
   const T *xs = (const T *)a->x;
   if (!sorted) {
-    hipLaunchKernelGGL(gather_sorted_kernel<T>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock),
-                       0, st, (const T *)a->x, res.perm, a->n, (T *)p.xs);
+    TMP_LAUNCH(gather_sorted_kernel<T>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock), st, (const T *)a->x, res.perm, a->n, (T *)p.xs);
     xs = (const T *)p.xs;
   }
   RsOut<T> o;
@@ -425,7 +424,7 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
   int grid = (int)((a->n + RK_ROWS - 1) / RK_ROWS);
-  hipLaunchKernelGGL(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), 0, st, res.comp, res.perm,
+  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm,
                      xs, a->n, lay, (uint64_t)a->range_back_secs, o);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

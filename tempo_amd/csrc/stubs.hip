@@ -11,5 +11,3 @@ using namespace tmp;
 STUB(tmp_ema, tmp_ema_args)
 STUB(tmp_lookback, tmp_lookback_args)
 STUB(tmp_resample, tmp_resample_args)
-STUB(tmp_hash_partition, tmp_partition_args)
-extern "C" int32_t tmp_key_owner(int32_t key, int32_t n_parts) { return (int32_t)((uint32_t)key % (uint32_t)n_parts); }

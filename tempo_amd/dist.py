@@ -1,0 +1,48 @@
+"""Multi-GPU key shuffle: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Spark's Exchange hashpartitioning(partitionCols) in front of every Window / groupBy
+(python/tempo/tsdf.py:121, :571; python/tempo/resample.py:63) becomes one all-to-all per
+column: rows are bucketed on the device by owner = mix(key) % world_size
+(tmp_hash_partition), exchanged with all_to_all_single, and every later operator runs locally
+on the series a rank owns -- no other collective is on the data path.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _hip_partition(key, n_parts):
+    return ops.hash_partition(key, n_parts)
+
+
+def _hip_take(col, perm):
+    return ops.gather(col, perm, want_valid=False)[0]
+
+
+def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None):
+    """Send every row to the rank that owns its key.
+
+    key: int32 tensor of GLOBAL dictionary ids (the same id for the same key on every rank).
+    columns: list of 1-D tensors with one entry per row (1-, 4- or 8-byte element types).
+    Returns (key_local, columns_local, send_counts, recv_counts).
+    partition_fn / take_fn default to the HIP kernels; tests on CPU inject host equivalents.
+    """
+    world = dist.get_world_size(group)
+    partition_fn = partition_fn or _hip_partition
+    take_fn = take_fn or _hip_take
+    perm, counts = partition_fn(key, world)
+    send = counts.to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    send_l = [int(v) for v in send.cpu().tolist()]
+    recv_l = [int(v) for v in recv.cpu().tolist()]
+    n_recv = sum(recv_l)
+    out_cols = []
+    for col in [key] + list(columns):
+        staged = take_fn(col, perm)
+        got = torch.empty(n_recv, dtype=col.dtype, device=col.device)
+        dist.all_to_all_single(got, staged, output_split_sizes=recv_l, input_split_sizes=send_l,
+                               group=group)
+        out_cols.append(got)
+    return out_cols[0], out_cols[1:], send_l, recv_l
