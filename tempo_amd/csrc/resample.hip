@@ -1,0 +1,328 @@
+// resample: tumbling-bucket aggregation.  Replaces window(ts, "<n> <unit>") +
+// groupBy(partitionCols, agg_key).agg(...) of python/tempo/resample.py:25-117.
+//
+// Rows are ordered by (key, ts); a bucket is a run of rows with equal key and equal
+// floor(ts / dur).  Pass 1 flags run heads and counts them per block, pass 2 turns the counts
+// into offsets, pass 3 writes each run's first position, and pass 4 gives one wave to each
+// bucket: lanes stride over the run, reduce with wave shuffles and lane 0 writes the result.
+#include <string.h>
+
+#include "common.h"
+
+namespace tmp {
+
+constexpr int RB_ROWS = 1024;
+constexpr int RB_THREADS = 256;
+
+__device__ __forceinline__ bool bucket_head(const uint64_t *comp, int64_t i, const Layout &lay,
+                                            int64_t dur) {
+  if (i == 0) return true;
+  uint64_t a = comp[i - 1], b = comp[i];
+  if (lay.key_of(a) != lay.key_of(b)) return true;
+  return floordiv_i64(lay.prim_of(a), dur) != floordiv_i64(lay.prim_of(b), dur);
+}
+
+__global__ __launch_bounds__(RB_THREADS) void bucket_count_kernel(const uint64_t *comp, int64_t n,
+                                                                  Layout lay, int64_t dur,
+                                                                  uint32_t *block_counts) {
+  __shared__ uint32_t wsum[RB_THREADS / 64];
+  int64_t t0 = (int64_t)blockIdx.x * RB_ROWS;
+  uint32_t heads = 0;
+  for (int r = 0; r < RB_ROWS / RB_THREADS; ++r) {
+    int64_t i = t0 + r * RB_THREADS + threadIdx.x;
+    if (i < n && bucket_head(comp, i, lay, dur)) ++heads;
+  }
+  for (int o = 32; o > 0; o >>= 1) heads += __shfl_down(heads, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = heads;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < RB_THREADS / 64; ++w) t += wsum[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void bucket_offsets_kernel(uint32_t *block_counts, int nblocks,
+                                                              int64_t *out_count, uint32_t *bstart,
+                                                              int64_t n) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    int i = base + tid;
+    uint32_t v = i < nblocks ? block_counts[i] : 0u;
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wp = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      uint32_t t = wave_tot[w];
+      if (w < wave) wp += t;
+      tot += t;
+    }
+    if (i < nblocks) block_counts[i] = carry_s + wp + inc - v;
+    __syncthreads();
+    if (tid == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *out_count = (int64_t)carry_s;
+    bstart[carry_s] = (uint32_t)n;  // sentinel: end of the last bucket
+  }
+}
+
+__global__ __launch_bounds__(RB_THREADS) void bucket_starts_kernel(const uint64_t *comp, int64_t n,
+                                                                   Layout lay, int64_t dur,
+                                                                   const uint32_t *block_offsets,
+                                                                   uint32_t *bstart, int32_t *out_key,
+                                                                   int64_t *out_start) {
+  __shared__ uint32_t wsum[RB_THREADS / 64];
+  int64_t t0 = (int64_t)blockIdx.x * RB_ROWS;
+  uint32_t base = block_offsets[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = 0; r < RB_ROWS / RB_THREADS; ++r) {
+    int64_t i = t0 + r * RB_THREADS + threadIdx.x;
+    bool head = i < n && bucket_head(comp, i, lay, dur);
+    uint64_t bal = __ballot(head);
+    uint32_t before = (uint32_t)__popcll(bal & (lane ? (~0ull >> (64 - lane)) : 0ull));
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t wp = 0, tot = 0;
+    for (int w = 0; w < RB_THREADS / 64; ++w) {
+      if (w < wave) wp += wsum[w];
+      tot += wsum[w];
+    }
+    if (head) {
+      uint32_t b = base + wp + before;
+      bstart[b] = (uint32_t)i;
+      uint64_t c = comp[i];
+      out_key[b] = (int32_t)lay.key_of(c);
+      out_start[b] = floordiv_i64(lay.prim_of(c), dur) * dur;  // ts - ((ts mod dur) + dur) mod dur
+    }
+    base += tot;
+    __syncthreads();
+  }
+}
+
+struct ColPtrs {
+  const void *col[TMP_MAX_COLS];
+  const uint8_t *valid[TMP_MAX_COLS];
+  uint8_t is_i64[TMP_MAX_COLS];
+};
+
+// Spark ordering of one cell against another: NULL smallest, NaN greatest, -0.0 == 0.0.
+__device__ __forceinline__ int cmp_cell(const ColPtrs &c, int k, uint32_t a, uint32_t b) {
+  bool va = !c.valid[k] || c.valid[k][a], vb = !c.valid[k] || c.valid[k][b];
+  if (va != vb) return va ? 1 : -1;
+  if (!va) return 0;
+  if (c.is_i64[k]) {
+    int64_t x = ((const int64_t *)c.col[k])[a], y = ((const int64_t *)c.col[k])[b];
+    return x < y ? -1 : (x > y ? 1 : 0);
+  }
+  double x = ((const double *)c.col[k])[a], y = ((const double *)c.col[k])[b];
+  if (x == y) return 0;
+  if (x != x) return (y != y) ? 0 : 1;
+  if (y != y) return -1;
+  return x < y ? -1 : 1;
+}
+
+__device__ __forceinline__ bool dlt(double a, double b) {  // a < b, NaN greatest
+  if (a != a) return false;
+  if (b != b) return true;
+  return a < b;
+}
+
+// floor / ceil: the row with the smallest / largest (ts, cols...) tuple.  Rows are ordered by
+// ts, so only the rows tying with the first / last ts of the bucket compete.
+__global__ __launch_bounds__(RB_THREADS) void bucket_pick_kernel(const uint64_t *comp,
+                                                                 const uint32_t *perm, Layout lay,
+                                                                 const uint32_t *bstart,
+                                                                 const int64_t *count, int func,
+                                                                 int n_cols, ColPtrs cols,
+                                                                 int32_t *out_row) {
+  int64_t nb = *count;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int low = lay.low_bits;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += stride) {
+    int64_t lo = bstart[b], hi = bstart[b + 1];  // [lo, hi)
+    int64_t best_pos;
+    if (func == TMP_FUNC_FLOOR) {
+      best_pos = lo;
+      uint64_t k0 = comp[lo] >> low;
+      for (int64_t j = lo + 1; j < hi && (comp[j] >> low) == k0; ++j) {
+        int c = 0;
+        for (int k = 0; c == 0 && k < n_cols; ++k) c = cmp_cell(cols, k, perm[j], perm[best_pos]);
+        if (c < 0) best_pos = j;
+      }
+    } else {
+      best_pos = hi - 1;
+      uint64_t k0 = comp[hi - 1] >> low;
+      int64_t first = hi - 1;
+      while (first > lo && (comp[first - 1] >> low) == k0) --first;
+      best_pos = first;
+      for (int64_t j = first + 1; j < hi; ++j) {
+        int c = 0;
+        for (int k = 0; c == 0 && k < n_cols; ++k) c = cmp_cell(cols, k, perm[j], perm[best_pos]);
+        if (c > 0) best_pos = j;
+      }
+    }
+    out_row[b] = (int32_t)perm[best_pos];
+  }
+}
+
+// mean / min / max: one wave per bucket and column.
+__global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_t *perm,
+                                                                   const uint32_t *bstart,
+                                                                   const int64_t *count, int func,
+                                                                   int n_cols, ColPtrs cols,
+                                                                   int64_t cap, double *out_f64,
+                                                                   int64_t *out_i64,
+                                                                   uint8_t *out_valid) {
+  const int64_t nb = *count;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
+    int64_t lo = bstart[b], hi = bstart[b + 1];
+    for (int k = 0; k < n_cols; ++k) {
+      const uint8_t *valid = cols.valid[k];
+      const bool is_i = cols.is_i64[k];
+      double sum = 0.0, dbest = 0.0;
+      int64_t ibest = 0, cnt = 0;
+      bool have = false;
+      for (int64_t j = lo + lane; j < hi; j += 64) {
+        uint32_t r = perm[j];
+        if (valid && !valid[r]) continue;
+        ++cnt;
+        if (is_i) {
+          int64_t v = ((const int64_t *)cols.col[k])[r];
+          sum += (double)v;
+          if (!have || (func == TMP_FUNC_MIN ? v < ibest : v > ibest)) ibest = v;
+        } else {
+          double v = ((const double *)cols.col[k])[r];
+          sum += v;
+          if (!have || (func == TMP_FUNC_MIN ? dlt(v, dbest) : dlt(dbest, v))) dbest = v;
+        }
+        have = true;
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        double s2 = __shfl_down(sum, o, 64);
+        int64_t c2 = __shfl_down(cnt, o, 64);
+        double d2 = __shfl_down(dbest, o, 64);
+        int64_t i2 = __shfl_down(ibest, o, 64);
+        int h2 = __shfl_down((int)have, o, 64);
+        sum += s2;
+        cnt += c2;
+        if (h2) {
+          if (is_i) {
+            if (!have || (func == TMP_FUNC_MIN ? i2 < ibest : i2 > ibest)) ibest = i2;
+          } else {
+            if (!have || (func == TMP_FUNC_MIN ? dlt(d2, dbest) : dlt(dbest, d2))) dbest = d2;
+          }
+          have = true;
+        }
+      }
+      if (lane == 0) {
+        int64_t o = (int64_t)k * cap + b;
+        out_valid[o] = cnt > 0;
+        double f = 0.0;
+        int64_t iv = 0;
+        if (cnt > 0) {
+          if (func == TMP_FUNC_MEAN) f = sum / (double)cnt;
+          else if (is_i) iv = ibest;
+          else f = dbest;
+        }
+        out_f64[o] = f;
+        out_i64[o] = iv;
+      }
+    }
+  }
+}
+
+struct RbPlan {
+  OrderBuffers ob;
+  uint32_t *block_counts;
+  uint32_t *bstart;
+  int nblocks;
+};
+
+static void rb_plan(const tmp_resample_args *a, Workspace &ws, RbPlan *p) {
+  order_plan(a->n, ws, &p->ob);
+  size_t cnt = (size_t)(a->n > 0 ? a->n : 1);
+  p->nblocks = (int)((cnt + RB_ROWS - 1) / RB_ROWS);
+  p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
+  p->bstart = ws.take<uint32_t>(cnt + 1);
+}
+
+}  // namespace tmp
+
+using namespace tmp;
+
+extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  RbPlan p;
+  rb_plan(a, ws, &p);
+  return ws.off;
+}
+
+extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_resample: null args");
+  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31) - 1, TMP_EINVAL, "tmp_resample: row count must be in [0, 2^31-1)");
+  TMP_REQUIRE(a->dur_us > 0, TMP_EINVAL, "tmp_resample: dur_us must be positive");
+  TMP_REQUIRE(a->func >= TMP_FUNC_FLOOR && a->func <= TMP_FUNC_CEIL, TMP_EINVAL, "tmp_resample: bad func");
+  TMP_REQUIRE(a->n_cols >= 0 && a->n_cols <= TMP_MAX_COLS, TMP_EINVAL, "tmp_resample: n_cols must be in [0, %d]",
+              TMP_MAX_COLS);
+  TMP_REQUIRE(a->out_count, TMP_EINVAL, "tmp_resample: out_count is null");
+  hipStream_t st = (hipStream_t)stream;
+  TMP_CHECK_HIP(hipMemsetAsync(a->out_count, 0, sizeof(int64_t), st));
+  if (a->n == 0) return TMP_OK;
+  bool reduce = a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX || a->func == TMP_FUNC_MEAN;
+  TMP_REQUIRE(a->ts && a->out_key && a->out_start, TMP_EINVAL, "tmp_resample: null pointer");
+  TMP_REQUIRE(!reduce || a->n_cols == 0 || (a->out_f64 && a->out_i64 && a->out_valid), TMP_EINVAL,
+              "tmp_resample: reduce outputs missing");
+  TMP_REQUIRE(reduce || a->out_row, TMP_EINVAL, "tmp_resample: out_row is null");
+  TMP_REQUIRE(a->n_cols == 0 || (a->cols && a->col_is_i64 && a->col_valid), TMP_EINVAL,
+              "tmp_resample: column arrays missing");
+  Workspace ws(workspace, workspace_bytes);
+  RbPlan p;
+  rb_plan(a, ws, &p);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
+  OrderSpec s;
+  memset(&s, 0, sizeof(s));
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1;
+  Layout lay;
+  OrderResult res;
+  TMP_TRY(order_single(s, p.ob, &lay, &res, st));
+  ColPtrs cp;
+  memset(&cp, 0, sizeof(cp));
+  for (int k = 0; k < a->n_cols; ++k) {
+    TMP_REQUIRE(a->cols[k] != nullptr, TMP_EINVAL, "tmp_resample: column %d is null", k);
+    cp.col[k] = a->cols[k];
+    cp.valid[k] = a->col_valid[k];
+    cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
+  }
+  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+             p.block_counts);
+  TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
+             p.bstart, a->n);
+  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+             p.block_counts, p.bstart, a->out_key, a->out_start);
+  if (reduce) {
+    if (a->n_cols > 0)
+      TMP_LAUNCH(bucket_reduce_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
+                 p.bstart, a->out_count, a->func, a->n_cols, cp, a->n, a->out_f64, a->out_i64, a->out_valid);
+  } else {
+    TMP_LAUNCH(bucket_pick_kernel, dim3(grid_for(a->n, RB_THREADS * 4, 8192)), dim3(RB_THREADS), st, res.comp,
+               res.perm, lay, p.bstart, a->out_count, a->func, a->n_cols, cp, a->out_row);
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}

@@ -1,0 +1,159 @@
+"""HIP EMA / withLookbackFeatures / resample / key bucketing against the CPU oracle, through
+the C ABI.  EMA and lookback are bit-exact (same taps, same add order / pure copies); resample
+bucket membership and min/max/floor/ceil are bit-exact, means within 1e-9 relative."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+BASE = 1_596_240_000_000_000
+
+
+def _dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tempo_amd import ops
+    return ops
+
+
+def _series(rng, n, nkeys, with_seq, sort=False, step_us=400_000, span=3000):
+    key = rng.integers(0, nkeys, n).astype(np.int32)
+    ts = BASE + rng.integers(0, span, n) * step_us
+    seq = rng.integers(-5, 50, n) if with_seq else None
+    seq_valid = (rng.random(n) >= 0.1).astype(np.uint8) if with_seq else None
+    if sort:
+        o = np.lexsort((ts, key))
+        key, ts = key[o], ts[o]
+    return key, ts, seq, seq_valid
+
+
+@pytest.mark.parametrize("seed,window,with_seq", [(0, 30, False), (1, 5, True), (2, 1, False), (3, 200, True)])
+def test_ema_bit_exact(orc, ops, seed, window, with_seq):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 40_000))
+    key, ts, seq, seq_valid = _series(rng, n, 6, with_seq)
+    x = rng.normal(0, 3, n)
+    xv = (rng.random(n) >= 0.1).astype(np.uint8)
+    perm, out = ops.ema(_dev(key), _dev(ts), _dev(x), _dev(xv), 6, window=window, exp_factor=0.2,
+                        seq=_dev(seq), seq_valid=_dev(seq_valid))
+    operm, oout = orc.ema(key, ts, x, xv, window, 0.2, seq=seq, seq_valid=seq_valid)
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), operm)
+    assert np.array_equal(out.cpu().numpy(), oout)  # same weights, same add order
+
+
+def test_ema_golden_scala_vector(ops, golden):
+    from conftest import ts_us
+    fx = golden["ema_scala"]
+    sym = [r[0] for r in fx["data"]]
+    key = np.array([sorted(set(sym)).index(s) for s in sym], np.int32)
+    ts = np.array([ts_us(r[1]) for r in fx["data"]])
+    x = np.array([r[2] for r in fx["data"]])
+    perm, out = ops.ema(_dev(key), _dev(ts), _dev(x), None, 2, window=fx["python_window"],
+                        exp_factor=fx["exp_factor"])
+    assert perm.cpu().numpy().tolist() == list(range(6))
+    assert out.cpu().numpy().tolist() == fx["expected_ema"]
+
+
+def test_ema_presorted_single_series(orc, ops):
+    rng = np.random.default_rng(5)
+    n = 50_000
+    ts = BASE + np.arange(n) * 5_000  # 5 ms sampling: many rows share a floor-second
+    x = rng.normal(-1.7, 3.86, n)
+    perm, out = ops.ema(None, _dev(ts), _dev(x), None, 1, window=30)
+    operm, oout = orc.ema(None, ts, x, None, 30, 0.2)
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), operm)
+    assert np.array_equal(out.cpu().numpy(), oout)
+
+
+@pytest.mark.parametrize("seed,L,exact,with_seq", [(0, 10, True, False), (1, 3, False, True), (2, 1, True, True),
+                                                   (3, 40, False, False)])
+def test_lookback(orc, ops, seed, L, exact, with_seq):
+    rng = np.random.default_rng(20 + seed)
+    n = int(rng.integers(1, 30_000))
+    key, ts, seq, seq_valid = _series(rng, n, 5, with_seq)
+    xs = [rng.normal(0, 1, n), rng.normal(5, 2, n), rng.integers(0, 9, n).astype(np.float64)]
+    xv = [None, (rng.random(n) >= 0.2).astype(np.uint8), None]
+    rows, lens, feat, fv = ops.lookback(_dev(key), _dev(ts), [_dev(x) for x in xs], [_dev(v) for v in xv], 5, L,
+                                        exact_size=exact, seq=_dev(seq), seq_valid=_dev(seq_valid))
+    operm, olen, ofeat, ofv = orc.lookback(key, ts, xs, xv, L, seq=seq, seq_valid=seq_valid)
+    if exact:
+        keep = olen == L
+        assert np.array_equal(rows.cpu().numpy().astype(np.int64), operm[keep])
+        assert np.array_equal(feat.cpu().numpy(), ofeat[keep])
+        assert np.array_equal(fv.cpu().numpy(), ofv[keep])
+    else:
+        assert np.array_equal(rows.cpu().numpy().astype(np.int64), operm)
+        assert np.array_equal(lens.cpu().numpy(), olen)
+        assert np.array_equal(feat.cpu().numpy(), ofeat)
+        assert np.array_equal(fv.cpu().numpy(), ofv)
+
+
+@pytest.mark.parametrize("func", ["mean", "min", "max", "floor", "ceil"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_resample(orc, ops, func, seed):
+    rng = np.random.default_rng(40 + seed)
+    n = int(rng.integers(1, 60_000))
+    key = rng.integers(0, 9, n).astype(np.int32)
+    ts = BASE + rng.integers(-2000, 20_000, n) * 5_000 * (1 + seed * 200)
+    if seed == 1:
+        ts = ts - 2 * BASE  # pre-epoch timestamps: floor-mod bucket rule
+    a = np.round(rng.normal(-1.7, 3.86, n), 1)  # coarse values: ties in the struct ordering
+    b = rng.integers(-3, 4, n)
+    c = rng.normal(8.93, 2.26, n)
+    av = (rng.random(n) >= 0.2).astype(np.uint8)
+    cols, valid = [a, b, c], [av, None, None]
+    dur = 60_000_000
+    r = ops.resample(_dev(key), _dev(ts), 9, dur, func, [_dev(x) for x in cols], [_dev(v) for v in valid])
+    o = orc.resample(key, ts, dur, func, cols, valid)
+    assert r["n"] == o["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), o["key"])
+    assert np.array_equal(r["start"].cpu().numpy(), o["start"])  # bucket membership bit-exact
+    if func in ("floor", "ceil"):
+        assert np.array_equal(r["row"].cpu().numpy().astype(np.int64), o["row"])
+        return
+    assert np.array_equal(r["valid"].cpu().numpy(), o["valid"])
+    if func == "mean":
+        np.testing.assert_allclose(r["f64"].cpu().numpy(), o["f64"], rtol=1e-9, atol=1e-12)
+    else:
+        assert np.array_equal(r["f64"].cpu().numpy(), o["f64"])
+        assert np.array_equal(r["i64"].cpu().numpy(), o["i64"])
+
+
+def test_resample_golden(ops, golden):
+    from conftest import ts_us
+    fx = golden["resample"]
+    ts = np.array([ts_us(r[2]) for r in fx["data"]])
+    key = np.zeros(len(ts), np.int32)
+    pr = np.array([r[3] for r in fx["data"]], np.float32).astype(np.float64)
+    pr2 = np.array([r[4] for r in fx["data"]], np.float32).astype(np.float64)
+    r = ops.resample(_dev(key), _dev(ts), 1, 60_000_000, "floor", [_dev(pr), _dev(pr2)], [None, None])
+    e = fx["floor_min"]["expected"]
+    assert r["n"] == len(e)
+    rows = r["row"].cpu().numpy()
+    for b, erow in enumerate(e):
+        assert int(r["start"][b]) == ts_us(erow[1])
+        assert np.float32(pr[rows[b]]) == np.float32(erow[2]) and pr2[rows[b]] == erow[4]
+    r = ops.resample(_dev(key), _dev(ts), 1, 300_000_000, "mean", [_dev(pr), _dev(pr2)], [None, None])
+    e = fx["mean_5min"]["expected"]
+    assert r["n"] == len(e)
+    f = r["f64"].cpu().numpy()
+    for b, erow in enumerate(e):
+        assert int(r["start"][b]) == ts_us(erow[1])
+        assert round(float(f[0][b]), 2) == erow[3] and f[1][b] == erow[4]
+
+
+def test_hash_partition_matches_host_owner(ops):
+    from tempo_amd import _lib
+    rng = np.random.default_rng(7)
+    n, parts = 100_000, 8
+    key = rng.integers(0, 5000, n).astype(np.int32)
+    perm, counts = ops.hash_partition(_dev(key), parts)
+    perm, counts = perm.cpu().numpy(), counts.cpu().numpy()
+    owner = np.array([_lib.lib().tmp_key_owner(int(k), parts) for k in range(5000)])[key]
+    assert np.array_equal(counts, np.bincount(owner, minlength=parts))
+    assert np.array_equal(perm, np.argsort(owner, kind="stable"))
