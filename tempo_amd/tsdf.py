@@ -1,0 +1,291 @@
+"""TSDF: the reference's time-series DataFrame API on the MI355X engine.
+
+Same class, method names, arguments, column naming and error behaviour as
+python/tempo/tsdf.py for the hot path (asofJoin incl. the tsPartitionVal/fraction skew mode,
+withRangeStats, EMA, withLookbackFeatures, resample); `df` is a pandas DataFrame (or a pyarrow
+Table) instead of a Spark DataFrame.  Every O(rows) computation runs in libtempo_hip.so on the
+GPU; this module only re-encodes columns, names outputs and raises the reference's errors.
+"""
+import logging
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import columns as col
+from . import ops
+from . import resample as rs
+
+logger = logging.getLogger(__name__)
+
+_SUMMARIZABLE = ['int', 'bigint', 'float', 'double']  # python/tempo/tsdf.py:697
+
+
+class TSDF:
+
+    def __init__(self, df, ts_col="event_ts", partition_cols=None, sequence_col=None):
+        """python/tempo/tsdf.py:24-36."""
+        df = col.to_pandas(df)
+        self.ts_col = self.__validated_column(df, ts_col)
+        self.partitionCols = [] if partition_cols is None else self.__validated_columns(df, partition_cols)
+        self.df = df
+        self.sequence_col = '' if sequence_col is None else sequence_col
+
+    ##
+    ## Helper functions
+    ##
+
+    def __validated_column(self, df, colname):  # tsdf.py:45-50
+        if type(colname) != str:
+            raise TypeError(f"Column names must be of type str; found {type(colname)} instead!")
+        if colname.lower() not in [c.lower() for c in df.columns]:
+            raise ValueError(f"Column {colname} not found in Dataframe")
+        return colname
+
+    def __validated_columns(self, df, colnames):  # tsdf.py:52-64
+        if type(colnames) == str:
+            colnames = [colnames]
+        if colnames is None:
+            colnames = []
+        elif type(colnames) != list:
+            raise TypeError(f"Columns must be of type list, str, or None; found {type(colnames)} instead!")
+        for c in colnames:
+            self.__validated_column(df, c)
+        return colnames
+
+    def __checkPartitionCols(self, tsdf_right):  # tsdf.py:66-69
+        for left_col, right_col in zip(self.partitionCols, tsdf_right.partitionCols):
+            if left_col != right_col:
+                raise ValueError("left and right dataframe partition columns should have same name in same order")
+
+    def __validateTsColMatch(self, right_tsdf):  # tsdf.py:71-75
+        left_ts_datatype = col.spark_dtype(self.df[self.ts_col])
+        right_ts_datatype = col.spark_dtype(right_tsdf.df[right_tsdf.ts_col])
+        if left_ts_datatype != right_ts_datatype:
+            raise ValueError("left and right dataframe timestamp index columns should have same type")
+
+    @staticmethod
+    def __prefixed(name, prefix):  # tsdf.py:77-94: '' keeps the name, otherwise '<prefix>_<name>'
+        return name if prefix == '' else prefix + '_' + name
+
+    ##
+    ## AS-OF join
+    ##
+
+    def asofJoin(self, right_tsdf, left_prefix=None, right_prefix="right", tsPartitionVal=None, fraction=0.5,
+                 skipNulls=True, sql_join_opt=False, suppress_null_warning=False):
+        """AS-OF join (python/tempo/tsdf.py:463-560).  Every left row is joined with the latest
+        right row of the same partition key at or before it; with skipNulls each right column
+        independently takes its latest non-NULL value.  tsPartitionVal / fraction select the
+        time-bracketed ("skew") variant.  sql_join_opt (a Spark broadcast-join plan with
+        different semantics, tsdf.py:492-509) does not apply to this engine and is ignored."""
+        if tsPartitionVal is not None:
+            logger.warning("You are using the skew version of the AS OF join. This may result in null values if "
+                           "there are any values outside of the maximum lookback. For maximum efficiency, choose "
+                           "smaller values of maximum lookback, trading off performance and potential blank AS OF "
+                           "values for sparse keys")
+        self.__checkPartitionCols(right_tsdf)
+        self.__validateTsColMatch(right_tsdf)
+        if skipNulls is False and tsPartitionVal is not None:  # tsdf.py:123-125
+            raise ValueError("Disabling null skipping with a partition value is not supported yet.")
+        if tsPartitionVal is not None and not isinstance(tsPartitionVal, (int, float)):
+            raise TypeError("tsPartitionVal must be an int or a float")
+
+        left_df, right_df = self.df, right_tsdf.df
+        part = self.partitionCols
+        left_cols = [c for c in left_df.columns if c not in part]
+        right_cols = [c for c in right_df.columns if c not in part]
+        lname = {c: (self.__prefixed(c, left_prefix) if left_prefix is not None else c) for c in left_cols}
+        rname = {c: self.__prefixed(c, right_prefix) for c in right_cols}
+        clash = set(lname.values()) & set(rname.values())
+        if clash:
+            raise ValueError(f"duplicate column names after prefixing: {sorted(clash)}")
+
+        (key_l, key_r), n_keys = col.encode_keys([left_df, right_df], part)
+        ts_l, secs = col.ts_to_int64(left_df[self.ts_col])
+        ts_r, _ = col.ts_to_int64(right_df[right_tsdf.ts_col])
+        seq = seq_valid = None
+        if right_tsdf.sequence_col:
+            seq, seq_valid, kind = col.numeric_to_device(right_df[right_tsdf.sequence_col])
+            if kind != "i64":
+                seq = seq.to(torch.int64)
+
+        # encode every right column for the device gather; columns with NULLs get a mask slot
+        enc = {c: col.any_to_device(right_df[c]) for c in right_cols}
+        masks, mask_of = [], {}
+        if skipNulls:
+            for c in right_cols:
+                if enc[c][1] is not None:
+                    mask_of[c] = len(masks)
+                    masks.append(enc[c][1])
+        if len(masks) > 16:
+            raise NotImplementedError("asofJoin supports at most 16 right columns with NULLs per call")
+
+        row_idx, mask_idx, missing = ops.asof_join(
+            col.to_dev(key_l), col.to_dev(ts_l), col.to_dev(key_r), col.to_dev(ts_r), n_keys,
+            seq_r=seq, seq_r_valid=seq_valid, masks=masks, ts_is_seconds=secs,
+            ts_partition_val=tsPartitionVal, fraction=fraction)
+
+        out = {c: left_df[c].reset_index(drop=True) for c in part}
+        for c in left_cols:
+            out[lname[c]] = left_df[c].reset_index(drop=True).rename(lname[c])
+        for c in right_cols:
+            values, valid, decode = enc[c]
+            idx = mask_idx[mask_of[c]] if c in mask_of else row_idx
+            g, gv = ops.gather(values, idx, valid)
+            out[rname[c]] = decode(g.cpu().numpy(), gv.cpu().numpy().astype(bool)).rename(rname[c])
+        joined = pd.concat([out[k].rename(k) for k in out], axis=1)
+
+        if tsPartitionVal is not None and (not suppress_null_warning or logger.isEnabledFor(logging.WARNING)):
+            miss = missing.cpu().numpy()
+            for c in right_cols:  # tsdf.py:150-158
+                if miss[1 + mask_of[c]] if c in mask_of else miss[0]:
+                    logger.warning("Column " + rname[c] + " had no values within the lookback window. Consider "
+                                   "using a larger window to avoid missing values. If this is the first record "
+                                   "in the data frame, this warning can be ignored.")
+        return TSDF(joined, lname[self.ts_col], part)
+
+    ##
+    ## window ordering shared by withRangeStats / EMA / withLookbackFeatures (tsdf.py:563-580)
+    ##
+
+    def _order_inputs(self, with_seq):
+        (key,), n_keys = col.encode_keys([self.df], self.partitionCols)
+        ts, secs = col.ts_to_int64(self.df[self.ts_col])
+        seq = seq_valid = None
+        if with_seq and self.sequence_col:
+            seq, seq_valid, kind = col.numeric_to_device(self.df[self.sequence_col])
+            if kind != "i64":  # seq.cast("long") truncates
+                seq = seq.to(torch.int64)
+        return col.to_dev(key), col.to_dev(ts), secs, n_keys, seq, seq_valid
+
+    def withPartitionCols(self, partitionCols):  # tsdf.py:583-590
+        return TSDF(self.df, self.ts_col, partitionCols)
+
+    def select(self, *cols):  # tsdf.py:319-343
+        seq_col_stub = [] if bool(self.sequence_col) == False else [self.sequence_col]
+        mandatory_cols = [self.ts_col] + self.partitionCols + seq_col_stub
+        if set(mandatory_cols).issubset(set(cols)):
+            return TSDF(self.df[list(cols)], self.ts_col, self.partitionCols, self.sequence_col or None)
+        raise Exception("In TSDF's select statement original ts_col, partitionCols and seq_col_stub(optional) "
+                        "must be present")
+
+    def EMA(self, colName, window=30, exp_factor=0.2):
+        """Truncated exponential moving average (python/tempo/tsdf.py:615-635):
+        EMA_<colName> = sum_{i < window} exp_factor * (1 - exp_factor)**i * lag(colName, i), NULL or
+        missing lags contributing 0.  Rows come back in window order."""
+        emaColName = "_".join(["EMA", colName])
+        key, ts, secs, n_keys, seq, seq_valid = self._order_inputs(True)
+        x, x_valid, kind = col.numeric_to_device(self.df[colName])
+        if kind == "i64":
+            x = x.to(torch.float64)
+        perm, ema = ops.ema(key, ts, x, x_valid, n_keys, window=window, exp_factor=exp_factor,
+                            ts_is_seconds=secs, seq=seq, seq_valid=seq_valid)
+        df = self.df.iloc[perm.cpu().numpy()].reset_index(drop=True)
+        df[emaColName] = ema.cpu().numpy()
+        return TSDF(df, self.ts_col, self.partitionCols)
+
+    def withLookbackFeatures(self, featureCols, lookbackWindowSize, exactSize=True, featureColName="features"):
+        """2-D trailing feature tensor per row (python/tempo/tsdf.py:637-671).  Each cell of
+        `featureColName` is an array of shape [n_lookback, len(featureCols)], oldest row first.
+        exactSize=True keeps only rows with a full window and returns a DataFrame (as upstream)."""
+        key, ts, secs, n_keys, seq, seq_valid = self._order_inputs(True)
+        xs, xv = [], []
+        for c in featureCols:
+            x, v, kind = col.numeric_to_device(self.df[c])
+            xs.append(x.to(torch.float64) if kind == "i64" else x)
+            xv.append(v)
+        rows, lens, feat, fv = ops.lookback(key, ts, xs, xv, n_keys, lookbackWindowSize, exact_size=exactSize,
+                                            ts_is_seconds=secs, seq=seq, seq_valid=seq_valid)
+        rows = rows.cpu().numpy()
+        feat = feat.cpu().numpy()
+        if fv is not None:
+            feat = np.where(fv.cpu().numpy().astype(bool), feat, np.nan)
+        df = self.df.iloc[rows].reset_index(drop=True)
+        if exactSize:
+            cells = [feat[i] for i in range(len(rows))]
+        else:
+            ln = lens.cpu().numpy()
+            cells = [feat[i, :ln[i]] for i in range(len(rows))]
+        df[featureColName] = pd.Series(cells, dtype=object)
+        if exactSize:
+            return df
+        return TSDF(df, self.ts_col, self.partitionCols)
+
+    def withRangeStats(self, type='range', colsToSummarize=[], rangeBackWindowSecs=1000):
+        """Rolling mean/count/min/max/sum/stddev/zscore over the trailing rangeBackWindowSecs
+        seconds per partition key (python/tempo/tsdf.py:673-721).  Rows come back in window
+        order."""
+        if self.sequence_col:
+            # Spark rejects a RANGE frame with two ORDER BY keys (tsdf.py:684 notes the limitation)
+            raise ValueError("withRangeStats does not support a sequence column: a range window needs "
+                             "exactly one ordering expression")
+        if not colsToSummarize:
+            prohibited_cols = [self.ts_col.lower()] + [pc.lower() for pc in self.partitionCols]
+            colsToSummarize = [c for c in self.df.columns
+                               if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+        key, ts, secs, n_keys, _, _ = self._order_inputs(False)
+        # order the frame once; every per-column call then sees ordered input and skips its sort
+        perm = ops.sort_order(key, ts, n_keys, floor_seconds=not secs) if len(self.df) else None
+        if perm is not None:
+            order = perm.cpu().numpy()
+            key = ops.gather(key, perm, want_valid=False)[0] if key is not None else None
+            ts = ops.gather(ts, perm, want_valid=False)[0]
+        else:
+            order = np.arange(0)
+        df = self.df.iloc[order].reset_index(drop=True)
+        derived = {}
+        for metric in colsToSummarize:
+            s = df[metric]
+            x, x_valid, kind = col.numeric_to_device(s)
+            out = ops.range_stats(key, ts, x, x_valid, n_keys, rangeBackWindowSecs, ts_is_seconds=secs)
+            valid = out["valid"].cpu().numpy()
+            ok, sd_ok, z_ok = (valid & 1) != 0, (valid & 2) != 0, (valid & 4) != 0
+            mean = np.where(ok, out["mean"].cpu().numpy(), np.nan)
+            mn, mx, sm = out["min"].cpu().numpy(), out["max"].cpu().numpy(), out["sum"].cpu().numpy()
+            df['mean_' + metric] = mean
+            df['count_' + metric] = out["count"].cpu().numpy()
+            if kind == "i64":
+                as_in = (lambda v: pd.Series(v).astype(s.dtype) if ok.all()
+                         else pd.Series(v).astype("Int64").where(ok, pd.NA))
+                df['min_' + metric] = as_in(mn).values
+                df['max_' + metric] = as_in(mx).values
+                df['sum_' + metric] = (pd.Series(sm) if ok.all() else pd.Series(sm).astype("Int64").where(ok, pd.NA)).values
+            else:
+                df['min_' + metric] = np.where(ok, mn, np.nan).astype(s.dtype)
+                df['max_' + metric] = np.where(ok, mx, np.nan).astype(s.dtype)
+                df['sum_' + metric] = np.where(ok, sm, np.nan)
+            df['stddev_' + metric] = np.where(sd_ok, out["stddev"].cpu().numpy(), np.nan)
+            derived["zscore_" + metric] = np.where(z_ok, out["zscore"].cpu().numpy(), np.nan)
+        for name, vals in derived.items():  # tsdf.py:718-719: zscore columns come last
+            df[name] = vals
+        return TSDF(df, self.ts_col, self.partitionCols)
+
+    def resample(self, freq, func=None, metricCols=None, prefix=None, fill=None):
+        """Downsample to `freq` buckets with floor / min / max / mean / ceil
+        (python/tempo/tsdf.py:764-776)."""
+        rs.validateFuncExists(func)
+        enriched_df = rs.aggregate(self, freq, func, metricCols, prefix, fill)
+        return _ResampledTSDF(enriched_df, ts_col=self.ts_col, partition_cols=self.partitionCols, freq=freq,
+                              func=func)
+
+    def calc_bars(tsdf, freq, func=None, metricCols=None, fill=None):
+        """OHLC bars = floor / min / max / ceil per bucket joined on (key, ts)
+        (python/tempo/tsdf.py:813-826)."""
+        resample_open = tsdf.resample(freq=freq, func='floor', metricCols=metricCols, prefix='open', fill=fill)
+        resample_low = tsdf.resample(freq=freq, func='min', metricCols=metricCols, prefix='low', fill=fill)
+        resample_high = tsdf.resample(freq=freq, func='max', metricCols=metricCols, prefix='high', fill=fill)
+        resample_close = tsdf.resample(freq=freq, func='ceil', metricCols=metricCols, prefix='close', fill=fill)
+        join_cols = resample_open.partitionCols + [resample_open.ts_col]
+        bars = (resample_open.df.merge(resample_high.df, on=join_cols).merge(resample_low.df, on=join_cols)
+                .merge(resample_close.df, on=join_cols))
+        non_part_cols = set(bars.columns) - set(resample_open.partitionCols) - set([resample_open.ts_col])
+        sel_and_sort = resample_open.partitionCols + [resample_open.ts_col] + sorted(non_part_cols)
+        return TSDF(bars[sel_and_sort], resample_open.ts_col, resample_open.partitionCols)
+
+
+class _ResampledTSDF(TSDF):  # python/tempo/tsdf.py:905-909
+    def __init__(self, df, ts_col="event_ts", partition_cols=None, sequence_col=None, freq=None, func=None):
+        super(_ResampledTSDF, self).__init__(df, ts_col, partition_cols, sequence_col)
+        self.__freq = freq
+        self.__func = func

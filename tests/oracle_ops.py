@@ -1,0 +1,80 @@
+"""Test-only stand-in for tempo_amd.ops that answers with the CPU oracle on host tensors.
+
+Lets the CPU suite exercise the host logic of tempo_amd (column encoding, naming, errors, result
+assembly) without a GPU.  Never imported by the product."""
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+def _np(t):
+    return None if t is None else t.cpu().numpy()
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t if dtype is None else t.to(dtype)
+
+
+def sort_order(key, ts, n_keys, floor_seconds=False, seq=None, seq_valid=None):
+    perm, _ = oracle.window_order(_np(key), _np(ts), ts_is_seconds=not floor_seconds, seq=_np(seq),
+                                  seq_valid=_np(seq_valid))
+    return _t(perm, torch.int32)
+
+
+def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, masks=(), ts_is_seconds=False,
+              ts_partition_val=None, fraction=0.5):
+    nL, nR = ts_l.numel(), ts_r.numel()
+    kl = _np(key_l) if key_l is not None else np.zeros(nL, np.int32)
+    kr = _np(key_r) if key_r is not None else np.zeros(nR, np.int32)
+    idx, missing = oracle.asof_join(kl, _np(ts_l), kr, _np(ts_r), seq_r=_np(seq_r), seq_r_valid=_np(seq_r_valid),
+                                    valid_r=[None] + [_np(m) for m in masks], skip_nulls=True,
+                                    ts_is_seconds=ts_is_seconds, ts_partition_val=ts_partition_val, fraction=fraction)
+    return _t(idx[0], torch.int32), _t(idx[1:].reshape(len(masks), nL), torch.int32), _t(missing, torch.int32)
+
+
+def gather(src, idx, src_valid=None, want_valid=True):
+    i = idx.to(torch.int64)
+    ok = i >= 0
+    safe = i.clamp(min=0)
+    if src.numel() == 0:
+        out = torch.zeros(idx.numel(), dtype=src.dtype)
+    else:
+        out = src[safe]
+        if src_valid is not None:
+            ok = ok & (src_valid[safe] != 0)
+    out = torch.where(ok, out, torch.zeros_like(out))
+    return out, (ok.to(torch.uint8) if want_valid else None)
+
+
+def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=False):
+    r = oracle.range_stats(_np(key), _np(ts), _np(x), _np(x_valid), range_back_secs, ts_is_seconds=ts_is_seconds)
+    valid = r["stat_valid"] | (r["stddev_valid"] << 1) | (r["zscore_valid"] << 2)
+    out = {k: _t(r[k]) for k in ("mean", "count", "min", "max", "sum", "stddev", "zscore")}
+    out["perm"] = _t(r["perm"], torch.int32)
+    out["valid"] = _t(valid.astype(np.uint8))
+    return out
+
+
+def ema(key, ts, x, x_valid, n_keys, window=30, exp_factor=0.2, ts_is_seconds=False, seq=None, seq_valid=None):
+    perm, out = oracle.ema(_np(key), _np(ts), _np(x), _np(x_valid), window, exp_factor, ts_is_seconds=ts_is_seconds,
+                           seq=_np(seq), seq_valid=_np(seq_valid))
+    return _t(perm, torch.int32), _t(out)
+
+
+def lookback(key, ts, xs, xs_valid, n_keys, lookback_size, exact_size=True, ts_is_seconds=False, seq=None,
+             seq_valid=None):
+    perm, ln, feat, fv = oracle.lookback(_np(key), _np(ts), [_np(x) for x in xs], [_np(v) for v in xs_valid],
+                                         lookback_size, ts_is_seconds=ts_is_seconds, seq=_np(seq),
+                                         seq_valid=_np(seq_valid))
+    if exact_size:
+        keep = ln == lookback_size
+        return _t(perm[keep], torch.int32), None, _t(feat[keep]), _t(fv[keep])
+    return _t(perm, torch.int32), _t(ln), _t(feat), _t(fv)
+
+
+def resample(key, ts, n_keys, dur_us, func, cols, cols_valid):
+    r = oracle.resample(_np(key), _np(ts), dur_us, func, [_np(c) for c in cols], [_np(v) for v in cols_valid])
+    return dict(n=r["n"], key=_t(r["key"]), start=_t(r["start"]), f64=_t(r["f64"]), i64=_t(r["i64"]),
+                valid=_t(r["valid"]), row=_t(r["row"], torch.int32), is_i64=r["is_i64"])

@@ -1,0 +1,70 @@
+"""Host logic of tempo_amd.TSDF (column encoding, prefixes, output naming/dtypes, reference
+errors) on CPU: the device operators are swapped for the oracle by monkeypatching, so the same
+golden cases run without a GPU.  The GPU suite runs them on the real kernels."""
+import pytest
+import torch
+
+import oracle_ops
+import tsdf_golden_cases as cases
+
+
+@pytest.fixture()
+def host_tsdf(monkeypatch, orc):
+    import tempo_amd
+    from tempo_amd import columns, ops
+    monkeypatch.setattr(columns, "device", lambda: torch.device("cpu"))
+    for name in ("sort_order", "asof_join", "gather", "range_stats", "ema", "lookback", "resample"):
+        monkeypatch.setattr(ops, name, getattr(oracle_ops, name))
+    return tempo_amd.TSDF
+
+
+@pytest.mark.parametrize("case", cases.ALL_CASES, ids=lambda c: c.__name__)
+def test_reference_case_host_logic(host_tsdf, case):
+    case(host_tsdf)
+
+
+def test_ops_refuse_cpu_tensors():
+    """The product path has no CPU fallback: device operators reject host tensors outright."""
+    from tempo_amd import ops
+    ts = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(TypeError, match="no CPU path"):
+        ops.sort_order(None, ts, 1)
+    with pytest.raises(TypeError, match="no CPU path"):
+        ops.asof_join(None, ts, None, ts, 1)
+
+
+def test_device_required_without_gpu():
+    from tempo_amd import columns
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        columns.device()
+
+
+def test_freq_parsing_matches_reference_rules():
+    from tempo_amd import resample as rs
+    assert rs.checkAllowableFreq(None, "min") == (1, "min")
+    assert rs.checkAllowableFreq(None, "5 minutes") == ("5", "min")
+    assert rs.checkAllowableFreq(None, "2 HOURS") == ("2", "hour")
+    assert rs.checkAllowableFreq(None, "3 hr") == ("3", "hour")
+    assert rs.checkAllowableFreq(None, "30 seconds") == ("30", "sec")
+    assert rs.checkAllowableFreq(None, "1 day") == ("1", "day")
+    assert rs.checkAllowableFreq(None, "1 fortnight") is None  # upstream falls through, resample.py:127-134
+    assert rs.bucket_duration_us(None, "5 minutes")[0] == 300_000_000
+    assert rs.bucket_duration_us(None, "hr")[0] == 3_600_000_000
+    assert rs.bucket_duration_us(None, "day")[0] == 86_400_000_000
+    with pytest.raises(ValueError):
+        rs.checkAllowableFreq(None, "minutes")
+
+
+def test_key_encoding_is_shared_across_frames():
+    import pandas as pd
+    from tempo_amd import columns
+    a = pd.DataFrame({"k": ["x", "y", None], "j": [1, 1, 2]})
+    b = pd.DataFrame({"k": ["y", "z"], "j": [1, 2]})
+    (ca, cb), n = columns.encode_keys([a, b], ["k"])
+    assert ca[1] == cb[0] and len({*ca, *cb}) == n == 4  # NULL is its own key
+    (ca, cb), n = columns.encode_keys([a, b], ["k", "j"])
+    assert ca[1] == cb[0] and n == 4
+    (ca, cb), n = columns.encode_keys([a, b], [])
+    assert ca is None and cb is None and n == 1
