@@ -73,11 +73,12 @@ int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t workspace_byt
  * Replaces the union + Window(last(col, ignorenulls) over rows unboundedPreceding..current)
  * plan of TSDF.asofJoin / __getLastRightRow / __getTimePartitions:
  *   python/tempo/tsdf.py:463-560, :111-162, :164-190.
- * For every left row it returns which right row each joined column comes from:
- *   out_row_idx[i]          last right row visible to left row i (skipNulls=False value rule,
- *                           and the rule for columns without NULLs), or -1
- *   out_mask_idx[m*n_left+i] last visible right row whose mask m is valid (skipNulls=True rule
- *                           for a column with NULLs), or -1
+ * For every left row it returns which right row each joined column comes from, as one record
+ * of (1 + n_masks) int32 per left row (row-major, so a row's indices share a cache line):
+ *   out_idx[i*(1+n_masks)]     last right row visible to left row i (skipNulls=False value
+ *                              rule, and the rule for columns without NULLs), or -1
+ *   out_idx[i*(1+n_masks)+1+m] last visible right row whose mask m is valid (skipNulls=True
+ *                              rule for a column with NULLs), or -1
  *   out_missing[0]          1 if some left row has no visible right row
  *   out_missing[1+m]        1 if some left row has no visible right row with mask m valid
  *                           (the non_null_ct == 0 warning test, tsdf.py:142-158)
@@ -107,8 +108,7 @@ typedef struct {
   int32_t v_is_int;
   double ts_partition_val;
   double one_minus_fraction;
-  int32_t *out_row_idx;  /* [n_left] */
-  int32_t *out_mask_idx; /* [n_masks][n_left] */
+  int32_t *out_idx;      /* [n_left][1 + n_masks] */
   int32_t *out_missing;  /* [1 + n_masks] */
 } tmp_asof_args;
 
@@ -116,13 +116,14 @@ size_t tmp_asof_join_workspace_bytes(const tmp_asof_args *a);
 int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * Row gather: out[i] = idx[i] >= 0 ? src[idx[i]] : 0 ; out_valid[i] = idx[i] >= 0 &&
- * (src_valid == NULL || src_valid[idx[i]]).  elem_bytes in {1, 4, 8}.
+ * Row gather: with j = idx[i * idx_stride]: out[i] = j >= 0 ? src[j] : 0 ; out_valid[i] =
+ * j >= 0 && (src_valid == NULL || src_valid[j]).  elem_bytes in {1, 4, 8}; idx_stride (in
+ * int32 elements, >= 1) lets a column of tmp_asof_join's out_idx records be used directly.
  * Replaces the Project that materialises the joined right columns (tsdf.py:139,147) and the
  * row reordering implied by window operators.
  */
 int tmp_gather(const void *src, const uint8_t *src_valid, int32_t elem_bytes, const int32_t *idx,
-               int64_t n, void *out, uint8_t *out_valid, void *stream);
+               int64_t idx_stride, int64_t n, void *out, uint8_t *out_valid, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * withRangeStats: rolling RANGE-frame statistics.

@@ -29,8 +29,7 @@ class AsofArgs(C.Structure):
                 ("seq_right_valid", _vp), ("n_keys", C.c_int32), ("ts_is_seconds", C.c_int32),
                 ("n_masks", C.c_int32), ("masks", C.POINTER(_vp)), ("skew", C.c_int32),
                 ("v_is_int", C.c_int32), ("ts_partition_val", C.c_double),
-                ("one_minus_fraction", C.c_double), ("out_row_idx", _vp), ("out_mask_idx", _vp),
-                ("out_missing", _vp)]
+                ("one_minus_fraction", C.c_double), ("out_idx", _vp), ("out_missing", _vp)]
 
 
 class RangeStatsArgs(C.Structure):
@@ -80,7 +79,7 @@ SYMBOLS = {
     "tmp_sort_order": _OP(SortArgs),
     "tmp_asof_join_workspace_bytes": _WS(AsofArgs),
     "tmp_asof_join": _OP(AsofArgs),
-    "tmp_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int64, _vp, _vp, _vp]),
+    "tmp_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "tmp_range_stats_workspace_bytes": _WS(RangeStatsArgs),
     "tmp_range_stats": _OP(RangeStatsArgs),
     "tmp_ema_workspace_bytes": _WS(EmaArgs),

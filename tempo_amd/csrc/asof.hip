@@ -8,7 +8,8 @@
 //      mask, the last position at or before it whose mask bit is set;
 //   2. every left row binary-searches its position in the ordered right side (search range
 //      narrowed per block), applies the key / bracket visibility tests and scatters the
-//      matched right row ids back to the left table's own row order.
+//      matched right row ids back to the left table's own row order, one record of
+//      (1 + masks) ids per left row so that the random write touches one line.
 #include <string.h>
 
 #include "common.h"
@@ -199,7 +200,7 @@ constexpr int kMergeRows = 4;  // left rows per thread
 __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
-    SkewParams sp, int32_t *out_row_idx, int32_t *out_mask_idx, int32_t *out_missing) {
+    SkewParams sp, int32_t *out_idx, int32_t *out_missing) {
   __shared__ int64_t bounds[2];
   const int low = lay.low_bits;
   int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     int32_t row_src = -1;
     if (same && (!sp.enabled || bracket_visible(lay.prim_of(comp_r[jr]), part_l, sp)))
       row_src = (int32_t)perm_r[jr];
-    if (out_row_idx) out_row_idx[dst] = row_src;
+    int32_t *rec = out_idx + (size_t)dst * (1 + n_masks);
+    rec[0] = row_src;
     miss_row |= row_src < 0;
     for (int m = 0; m < n_masks; ++m) {
       int32_t src = -1;
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
             src = (int32_t)perm_r[j];
         }
       }
-      out_mask_idx[(size_t)m * n_left + dst] = src;
+      rec[1 + m] = src;
       miss_mask |= (uint32_t)(src < 0) << m;
     }
   }
@@ -284,8 +286,8 @@ static int asof_validate(const tmp_asof_args *a) {
               "tmp_asof_join: key columns must be given for both sides or neither");
   TMP_REQUIRE(a->n_left == 0 || a->ts_left, TMP_EINVAL, "tmp_asof_join: ts_left is null");
   TMP_REQUIRE(a->n_right == 0 || a->ts_right, TMP_EINVAL, "tmp_asof_join: ts_right is null");
-  TMP_REQUIRE(a->n_masks == 0 || (a->masks && a->out_mask_idx), TMP_EINVAL,
-              "tmp_asof_join: masks/out_mask_idx missing");
+  TMP_REQUIRE(a->n_masks == 0 || a->masks, TMP_EINVAL, "tmp_asof_join: masks missing");
+  TMP_REQUIRE(a->n_left == 0 || a->out_idx, TMP_EINVAL, "tmp_asof_join: out_idx is null");
   TMP_REQUIRE(a->out_missing, TMP_EINVAL, "tmp_asof_join: out_missing is null");
   if (a->skew) {
     TMP_REQUIRE(a->ts_partition_val == a->ts_partition_val && a->ts_partition_val != 0.0, TMP_EINVAL,
@@ -316,11 +318,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
               "tmp_asof_join: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
   if (a->n_right == 0) {  // nothing to match: every index is -1, everything is missing
     int grid = grid_for(a->n_left, kBlock * 4, 8192);
-    if (a->out_row_idx)
-      TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_row_idx, a->n_left, -1);
-    if (a->n_masks)
-      TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_mask_idx,
-                         a->n_left * a->n_masks, -1);
+    TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_idx, a->n_left * (1 + a->n_masks), -1);
     TMP_LAUNCH(fill_i32_kernel, dim3(1), dim3(64), st, a->out_missing, 1 + a->n_masks, 1);
     TMP_CHECK_HIP(hipGetLastError());
     return TMP_OK;
@@ -347,8 +345,8 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   Layout lay;
   TMP_TRY(order_make_layout(rs, both, a->n_masks, &lay));
   OrderResult lo, ro;
-  TMP_TRY(order_build(ls, lay, rl.unsorted == 0, p.lb, &lo, st));
-  TMP_TRY(order_build(rs, lay, rr.unsorted == 0, p.rb, &ro, st));
+  TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
+  TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
 
   if (a->n_masks > 0) {
     ScanGeom g = scan_geom(a->n_right);
@@ -367,8 +365,8 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   sp.one_minus_fraction = a->one_minus_fraction;
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
-                     ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_row_idx,
-                     a->out_mask_idx, a->out_missing);
+                     ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
+                     a->out_missing);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

@@ -95,8 +95,8 @@ struct RangeInfo {
   int64_t prim_max;
   int64_t seq_min;
   int64_t seq_max;
-  int32_t unsorted;
-  int32_t pad;
+  int32_t unsorted;       // rows are not in (key, primary, seq) order
+  int32_t time_unsorted;  // rows are not even in (primary, seq) order, keys ignored
 };
 
 struct OrderSpec {
@@ -127,8 +127,14 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b);
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st);
 int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st);
 int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layout *out);
-int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, OrderBuffers &b,
+// sorted: 0 = full sort, 1 = rows already in (key, primary, seq) order (no passes), 2 = rows in
+// (primary, seq) order with interleaved keys (a time-ordered feed): the stable passes over the
+// key bits alone finish the job.
+int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st);
+inline int sorted_mode(const RangeInfo &r) { return !r.unsorted ? 1 : (!r.time_unsorted ? 2 : 0); }
+int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                       hipStream_t st);
 // One-call form for ops that order a single table.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);

@@ -123,7 +123,7 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   TMP_TRY(order_read_ranges(p.ob, &r, st));
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   bool sorted = r.unsorted == 0;
-  TMP_TRY(order_build(s, lay, sorted, p.ob, &res, st));
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st));
   const double *xs = a->x;
   if (!sorted) {
     TMP_LAUNCH(take_sorted_kernel<double>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock), st, a->x,

@@ -1,6 +1,7 @@
 // Ordering step shared by every op: (key, primary[, seq]) -> 64-bit sort word -> stable LSD
 // radix sort of (sort word, row id) pairs.  Replaces Spark's Exchange + SortExec in front of
 // WindowExec / aggregates (python/tempo/tsdf.py:117-121, :563-572; resample.py:63).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -46,7 +47,7 @@ __global__ void range_init_kernel(RangeInfo *r) {
   r->seq_min = INT64_MAX;
   r->seq_max = INT64_MIN;
   r->unsorted = 0;
-  r->pad = 0;
+  r->time_unsorted = 0;
 }
 
 __device__ __forceinline__ int64_t wave_min(int64_t v) {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
                                                             const uint8_t *seq_valid,
                                                             RangeInfo *out) {
   int64_t pmin = INT64_MAX, pmax = INT64_MIN, smin = INT64_MAX, smax = INT64_MIN;
-  int bad = 0;
+  int bad = 0, tbad = 0;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
@@ -88,16 +89,19 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
     }
     if (i > 0) {  // lexicographic (key, primary, seq NULLS FIRST) against the previous row
       int32_t k0 = key ? key[i - 1] : 0, k1 = key ? key[i] : 0;
-      if (k0 != k1) bad |= k0 > k1;
-      else {
-        int64_t p0 = div == 1 ? ts[i - 1] : floordiv_i64(ts[i - 1], div);
-        if (p0 != p) bad |= p0 > p;
-        else if (seq) {
-          bool sv0 = !seq_valid || seq_valid[i - 1];
-          if (sv0 != sv) bad |= sv0;            // previous non-NULL, this one NULL
-          else if (sv) bad |= seq[i - 1] > s;
+      int64_t p0 = div == 1 ? ts[i - 1] : floordiv_i64(ts[i - 1], div);
+      int tcmp = p0 > p ? 1 : (p0 < p ? -1 : 0);  // (primary, seq) of the previous row vs this one
+      if (tcmp == 0 && seq) {
+        bool sv0 = !seq_valid || seq_valid[i - 1];
+        if (sv0 != sv) tcmp = sv0 ? 1 : -1;  // NULL sorts first
+        else if (sv) {
+          int64_t s0 = seq[i - 1];
+          tcmp = s0 > s ? 1 : (s0 < s ? -1 : 0);
         }
       }
+      tbad |= tcmp > 0;
+      if (k0 != k1) bad |= k0 > k1;
+      else bad |= tcmp > 0;
     }
   }
   pmin = wave_min(pmin);
@@ -105,12 +109,14 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
   smin = wave_min(smin);
   smax = wave_max(smax);
   bad = __any(bad);
+  tbad = __any(tbad);
   if ((threadIdx.x & 63) == 0) {
     if (pmin != INT64_MAX) atomicMin((long long *)&out->prim_min, (long long)pmin);
     if (pmax != INT64_MIN) atomicMax((long long *)&out->prim_max, (long long)pmax);
     if (smin != INT64_MAX) atomicMin((long long *)&out->seq_min, (long long)smin);
     if (smax != INT64_MIN) atomicMax((long long *)&out->seq_max, (long long)smax);
     if (bad) atomicOr(&out->unsorted, 1);
+    if (tbad) atomicOr(&out->time_unsorted, 1);
   }
 }
 
@@ -150,10 +156,6 @@ __global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, const int3
 // the same digit comes from wave-wide ballots (64 lanes) plus per-wave LDS counters, and the
 // tile is first reordered in LDS so that global stores go out in runs of equal digit.
 // ------------------------------------------------------------------------------------------
-constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
-constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAX_GRID = 1024;
 constexpr int RS_RADIX = 256;
 
@@ -162,8 +164,8 @@ struct SortGeom {
   int tiles_per_block;
 };
 
-static SortGeom sort_geom(int64_t n) {
-  int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+static SortGeom sort_geom(int64_t n, int tile) {
+  int64_t tiles = (n + tile - 1) / tile;
   if (tiles < 1) tiles = 1;
   SortGeom g;
   g.tiles_per_block = (int)((tiles + RS_MAX_GRID - 1) / RS_MAX_GRID);
@@ -171,10 +173,13 @@ static SortGeom sort_geom(int64_t n) {
   return g;
 }
 
+template <int RS_THREADS, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
                                                                 uint32_t *counts) {
+  constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+  constexpr int RS_WAVES = RS_THREADS / 64;
   __shared__ uint32_t hist[RS_WAVES][RS_RADIX];
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
@@ -187,9 +192,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
     atomicAdd(&hist[wave][d], 1u);
   }
   __syncthreads();
-  uint32_t c = 0;
-  for (int w = 0; w < RS_WAVES; ++w) c += hist[w][threadIdx.x];
-  counts[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = c;
+  for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
+    uint32_t c = 0;
+    for (int w = 0; w < RS_WAVES; ++w) c += hist[w][d];
+    counts[(size_t)d * gridDim.x + blockIdx.x] = c;
+  }
 }
 
 // Exclusive scan of `total` uint32 counters in place, one block.
@@ -230,18 +237,21 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
   }
 }
 
+template <int RS_THREADS, int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets) {
+  constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+  constexpr int RS_WAVES = RS_THREADS / 64;
   __shared__ uint64_t skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
   __shared__ uint32_t dstart[RS_RADIX];
   __shared__ uint32_t goff[RS_RADIX];
-  __shared__ uint32_t wtot[RS_WAVES];
+  __shared__ uint32_t wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
+  if (tid < RS_RADIX) goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
   volatile uint32_t *wh = &whist[wave][0];
   for (int t = 0; t < tiles_per_block; ++t) {
     int64_t tile_base = ((int64_t)blockIdx.x * tiles_per_block + t) * RS_TILE;
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     uint64_t k[RS_ITEMS];
     uint32_t v[RS_ITEMS];
     uint32_t rank[RS_ITEMS];
+    uint32_t cnt_inc = 0;
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
       int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
@@ -276,23 +287,29 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       rank[it] = prior + (uint32_t)__popcll(peers & lt_mask);
     }
     __syncthreads();
-    // digit `tid`: exclusive prefix of its count over the waves, then over the digits
+    // digit `tid` (first 256 threads): exclusive prefix of its count over the waves, then over
+    // the digits
     uint32_t cnt_d = 0;
-    for (int w = 0; w < RS_WAVES; ++w) {
-      uint32_t c = whist[w][tid];
-      whist[w][tid] = cnt_d;
-      cnt_d += c;
+    if (tid < RS_RADIX) {
+      for (int w = 0; w < RS_WAVES; ++w) {
+        uint32_t c = whist[w][tid];
+        whist[w][tid] = cnt_d;
+        cnt_d += c;
+      }
+      uint32_t inc = cnt_d;
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t tt = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += tt;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      cnt_inc = inc;
     }
-    uint32_t inc = cnt_d;
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t tt = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += tt;
-    }
-    if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    uint32_t wp = 0;
-    for (int w = 0; w < wave; ++w) wp += wtot[w];
-    dstart[tid] = wp + inc - cnt_d;
+    if (tid < RS_RADIX) {
+      uint32_t wp = 0;
+      for (int w = 0; w < wave; ++w) wp += wtot[w];
+      dstart[tid] = wp + cnt_inc - cnt_d;
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       }
     }
     __syncthreads();
-    goff[tid] += cnt_d;
+    if (tid < RS_RADIX) goff[tid] += cnt_d;
     __syncthreads();
   }
 }
@@ -380,18 +397,26 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 }
 
 // Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].
-int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st) {
-  SortGeom g = sort_geom(n);
+template <int THREADS, int ITEMS>
+static int radix_passes_cfg(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                            hipStream_t st) {
+  SortGeom g = sort_geom(n, THREADS * ITEMS);
   int cur = 0;
   for (int lo = lo_bit; lo < hi_bit; lo += 8) {
     int nbits = hi_bit - lo < 8 ? hi_bit - lo : 8;
     uint32_t mask = (1u << nbits) - 1;
-    TMP_LAUNCH(radix_hist_kernel, dim3(g.grid), dim3(RS_THREADS), st, b.comp[cur], n, lo, mask,
-               g.tiles_per_block, b.counts);
+    {
+      ProfScope ps("radix_hist_kernel", st);
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts);
+    }
     TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
-    TMP_LAUNCH(radix_scatter_kernel, dim3(g.grid), dim3(RS_THREADS), st, b.comp[cur], b.idx[cur],
-               b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits, g.tiles_per_block, b.counts);
+    {
+      ProfScope ps("radix_scatter_kernel", st);
+      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                         g.tiles_per_block, b.counts);
+    }
     cur ^= 1;
   }
   TMP_CHECK_HIP(hipGetLastError());
@@ -400,7 +425,21 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
   return TMP_OK;
 }
 
-int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, OrderBuffers &b,
+int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                       hipStream_t st) {
+  static int cfg = getenv("TMP_SORT_CFG") ? atoi(getenv("TMP_SORT_CFG")) : 0;
+  switch (cfg) {
+    case 1: return radix_passes_cfg<512, 8>(b, n, lo_bit, hi_bit, res, st);
+    case 2: return radix_passes_cfg<1024, 4>(b, n, lo_bit, hi_bit, res, st);
+    case 3: return radix_passes_cfg<512, 16>(b, n, lo_bit, hi_bit, res, st);
+    case 4: return radix_passes_cfg<256, 8>(b, n, lo_bit, hi_bit, res, st);
+    case 5: return radix_passes_cfg<1024, 8>(b, n, lo_bit, hi_bit, res, st);
+    case 6: return radix_passes_cfg<256, 16>(b, n, lo_bit, hi_bit, res, st);
+    default: return radix_passes_cfg<1024, 8>(b, n, lo_bit, hi_bit, res, st);
+  }
+}
+
+int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st) {
   res->comp = b.comp[0];
   res->perm = b.idx[0];
@@ -411,8 +450,8 @@ int order_build(const OrderSpec &s, const Layout &lay, bool already_sorted, Orde
   TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts, s.seq,
                      s.seq_valid, lay, s.n_masks, mp, b.comp[0], b.idx[0]);
   TMP_CHECK_HIP(hipGetLastError());
-  if (already_sorted) return TMP_OK;
-  return order_radix_passes(b, s.n, lay.low_bits, lay.total_bits(), res, st);
+  if (sorted == 1) return TMP_OK;
+  return order_radix_passes(b, s.n, sorted == 2 ? lay.key_shift() : lay.low_bits, lay.total_bits(), res, st);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
@@ -421,7 +460,7 @@ int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *
   RangeInfo r;
   TMP_TRY(order_read_ranges(b, &r, st));
   TMP_TRY(order_make_layout(s, r, s.n_masks, lay));
-  return order_build(s, *lay, r.unsorted == 0, b, res, st);
+  return order_build(s, *lay, sorted_mode(r), b, res, st);
 }
 
 }  // namespace tmp

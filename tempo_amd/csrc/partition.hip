@@ -41,9 +41,6 @@ __global__ void copy_u32_i32_kernel(const uint32_t *in, int32_t *out, int64_t n)
     out[i] = (int32_t)in[i];
 }
 
-int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st);
-
 }  // namespace tmp
 
 using namespace tmp;

@@ -3,14 +3,15 @@
 // (python/tempo/tsdf.py:673-721; ordering :563-572).
 //
 // Rows are ordered by (key, floor-second); the metric's validity bit rides in bit 0 of the
-// sort word.  A block owns 1024 consecutive output rows.  Its frames all lie inside one
-// contiguous extent [lo(first row), hi(last row)]; when the extent fits in LDS the block
-//   - loads the extent once, shifted by a block pivot (d = x - pivot),
-//   - builds inclusive prefix sums of d, d*d and the valid / non-finite counts in LDS,
-//   - builds a sparse table of minima / maxima over 16-row sub-blocks,
-// and every row then reads its frame as differences of prefixes and one range-min/max query.
-// Frames with non-finite values and blocks whose extent exceeds LDS take the exact
-// row-sequential path (Spark's own Welford recurrence).
+// sort word.  A block owns 1024 consecutive output rows and stages a region of up to 2560 rows
+// around them in LDS (32-bit relative sort words + metric, one coalesced read).  Straight from
+// the staging registers it reduces every 16-row sub-block (one DPP row) to sum(x - pivot),
+// sum((x - pivot)^2), counts, min and max; one wave turns the sums into prefixes over
+// sub-blocks, two waves build sparse tables over the minima / maxima.  Every row then finds its
+// frame by searching the staged sort words, walks the partial sub-blocks at both ends slot by
+// slot and takes the whole sub-blocks in between from the prefixes and the tables.
+// Frames that reach outside the region or hold non-finite values take the exact row-sequential
+// path (Spark's own Welford recurrence) from global memory.
 #include <string.h>
 
 #include "common.h"
@@ -18,11 +19,12 @@
 namespace tmp {
 
 constexpr int RK_ROWS = 1024;
-constexpr int RK_CAP = 3072;
-constexpr int RK_THREADS = 512;
+constexpr int RK_CAP = 2560;
+constexpr int RK_THREADS = 1024;
+constexpr int RK_FWD = 256;  // rows staged after the tile
 constexpr int RK_SB = 16;
-constexpr int RK_NSB = RK_CAP / RK_SB;  // 192
-constexpr int RK_LEVELS = 8;            // 2^7 < 192 <= 2^8
+constexpr int RK_NSB = RK_CAP / RK_SB;  // 160
+constexpr int RK_LEVELS = 8;            // 2^7 < 160 <= 2^8
 
 template <typename T>
 struct Ord;
@@ -133,21 +135,108 @@ __device__ __forceinline__ uint64_t frame_start_key(uint64_t k, uint64_t prim_ma
   return (k - rel) + (rel > w ? rel - w : 0);
 }
 
+// ---- 16-lane (one DPP row) inclusive scans: lane 15 of every row ends up with the row total.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int old, int v, bool bound_zero) {
+  return bound_zero ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true)
+                    : __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v, bool bound_zero) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = dpp_i32<CTRL>(lo, lo, bound_zero);
+  hi = dpp_i32<CTRL>(hi, hi, bound_zero);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v, bool bound_zero) {
+  int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+  lo = dpp_i32<CTRL>(lo, lo, bound_zero);
+  hi = dpp_i32<CTRL>(hi, hi, bound_zero);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+// row_shr:1/2/4/8 = 0x111 / 0x112 / 0x114 / 0x118
+#define TMP_ROW_SCAN(expr_shr)  \
+  expr_shr(0x111) expr_shr(0x112) expr_shr(0x114) expr_shr(0x118)
+
+__device__ __forceinline__ double row_sum_f64(double v) {
+#define S_(c) v += dpp_f64<c>(v, true);
+  TMP_ROW_SCAN(S_)
+#undef S_
+  return v;
+}
+__device__ __forceinline__ uint64_t row_sum_u64(uint64_t v) {
+#define S_(c) v += dpp_u64<c>(v, true);
+  TMP_ROW_SCAN(S_)
+#undef S_
+  return v;
+}
+__device__ __forceinline__ uint32_t row_sum_u32(uint32_t v) {
+#define S_(c) v += (uint32_t)dpp_i32<c>(0, (int)v, true);
+  TMP_ROW_SCAN(S_)
+#undef S_
+  return v;
+}
+
+// min / max over staged slots.  double: NULL slots hold NaN, and fmin / fmax return the other
+// operand for a NaN, so the identity is NaN (frames that hold real NaN / inf values never take
+// this path).  int64: identities are the type's extremes.
+template <typename T>
+struct MinMax;
+template <>
+struct MinMax<double> {
+  static __device__ __forceinline__ double null_slot() { return __builtin_nan(""); }
+  static __device__ __forceinline__ double min_identity() { return __builtin_nan(""); }
+  static __device__ __forceinline__ double max_identity() { return __builtin_nan(""); }
+  static __device__ __forceinline__ double mn(double a, double b) { return fmin(a, b); }
+  static __device__ __forceinline__ double mx(double a, double b) { return fmax(a, b); }
+  static __device__ __forceinline__ double row_min(double v) {
+#define S_(c) v = fmin(v, dpp_f64<c>(v, false));
+    TMP_ROW_SCAN(S_)
+#undef S_
+    return v;
+  }
+  static __device__ __forceinline__ double row_max(double v) {
+#define S_(c) v = fmax(v, dpp_f64<c>(v, false));
+    TMP_ROW_SCAN(S_)
+#undef S_
+    return v;
+  }
+};
+template <>
+struct MinMax<int64_t> {
+  static __device__ __forceinline__ int64_t null_slot() { return 0; }
+  static __device__ __forceinline__ int64_t min_identity() { return INT64_MAX; }
+  static __device__ __forceinline__ int64_t max_identity() { return INT64_MIN; }
+  static __device__ __forceinline__ int64_t mn(int64_t a, int64_t b) { return a < b ? a : b; }
+  static __device__ __forceinline__ int64_t mx(int64_t a, int64_t b) { return a > b ? a : b; }
+  static __device__ __forceinline__ int64_t row_min(int64_t v) {
+#define S_(c) { int64_t t = (int64_t)dpp_u64<c>((uint64_t)v, false); v = t < v ? t : v; }
+    TMP_ROW_SCAN(S_)
+#undef S_
+    return v;
+  }
+  static __device__ __forceinline__ int64_t row_max(int64_t v) {
+#define S_(c) { int64_t t = (int64_t)dpp_u64<c>((uint64_t)v, false); v = t > v ? t : v; }
+    TMP_ROW_SCAN(S_)
+#undef S_
+    return v;
+  }
+};
+
+constexpr uint32_t RK_SAT = 0x7fffffffu;  // saturated relative sort word
+
 template <typename T>
 struct RsShared {
   static constexpr bool kIntT = ((T)0.5 == (T)0);
-  T x[RK_CAP];
-  double ps[RK_CAP];
-  double pq[RK_CAP];
-  uint64_t pi[kIntT ? RK_CAP : 1];  // exact integer prefix, int64 metrics only
-  uint32_t pc[RK_CAP];   // low 16 bits: valid count, high 16 bits: non-finite count
-  T mn[RK_LEVELS][RK_NSB];
+  uint32_t ck[RK_CAP];       // ((sort word >> low) - base, saturated) << 1 | metric-not-NULL
+  T x[RK_CAP];               // metric; for double a NULL slot holds NaN
+  double bs[RK_NSB + 1];     // exclusive prefix over sub-blocks of sum(x - pivot)
+  double bq[RK_NSB + 1];     // ... of sum((x - pivot)^2)
+  uint64_t bi[kIntT ? RK_NSB + 1 : 1];  // ... of the exact integer sum (int64 metrics)
+  uint32_t bc[RK_NSB + 1];   // ... of counts: low 16 bits valid, high 16 bits non-finite
+  T mn[RK_LEVELS][RK_NSB];   // sparse tables over sub-block minima / maxima
   T mx[RK_LEVELS][RK_NSB];
-  double wave_s[RK_THREADS / 64];
-  double wave_q[RK_THREADS / 64];
-  uint64_t wave_i[RK_THREADS / 64];
-  uint32_t wave_c[RK_THREADS / 64];
-  int64_t ext[2];
   int pivot_at;
 };
 
@@ -163,221 +252,262 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   const uint64_t pmask = lay.prim_mask();
   const int64_t t0 = (int64_t)blockIdx.x * RK_ROWS;
   const int64_t t1 = t0 + RK_ROWS < n ? t0 + RK_ROWS : n;
-
-  // extent of the block: waves 0 and 1 search one end each (wave-uniform branches)
-  if (wave < 2) {
-    int64_t r;
-    if (wave == 0) {
-      uint64_t k = comp[t0] >> low;
-      r = lower_bound_k(comp, 0, t0, frame_start_key(k, pmask, w), low);
-    } else {
-      uint64_t k = comp[t1 - 1] >> low;
-      r = upper_bound_k(comp, t1 - 1, n, k, low) - 1;
-    }
-    if (lane == 0) s.ext[wave] = r;
-  }
+  // staged region [rs, re): the tile, RK_FWD rows after it (later same-second peers) and as many
+  // rows before it as fit
+  constexpr int kBack = RK_CAP - RK_ROWS - RK_FWD;
+  const int64_t rs = t0 - kBack > 0 ? t0 - kBack : 0;
+  const int64_t re = t0 + RK_ROWS + RK_FWD < n ? t0 + RK_ROWS + RK_FWD : n;
+  const int len = (int)(re - rs);
+  const uint64_t base = comp[rs] >> low;
   if (tid == 0) s.pivot_at = RK_CAP;
   __syncthreads();
-  const int64_t e0 = s.ext[0], e1 = s.ext[1];
-  const int64_t len = e1 - e0 + 1;
 
-  if (len > RK_CAP) {  // extent too long for LDS: exact sequential frames (block-uniform branch)
-    for (int64_t i = t0 + tid; i < t1; i += RK_THREADS) {
-      uint64_t k = comp[i] >> low;
-      int64_t lo = lower_bound_k(comp, e0, i, frame_start_key(k, pmask, w), low);
-      int64_t hi = upper_bound_k(comp, i, e1 + 1, k, low) - 1;
-      o.perm[i] = (int32_t)perm[i];
-      rs_row_serial<T>(comp, xs, lo, hi, i, o);
-    }
-    return;
-  }
-
-  // ---- load the extent; pick the pivot = first valid finite value
-  constexpr int kPer = RK_CAP / RK_THREADS;  // 6
+  // ---- stage the region: one coalesced read of sort words and metric values
+  constexpr int kPer = (RK_CAP + RK_THREADS - 1) / RK_THREADS;
   T xv[kPer];
   bool ok[kPer], fin[kPer];
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     int e = r * RK_THREADS + tid;
-    bool in = e < len;
-    uint64_t cw = in ? comp[e0 + e] : 0ull;
-    ok[r] = in && (cw & 1ull);
-    xv[r] = ok[r] ? xs[e0 + e] : (T)0;
-    fin[r] = ok[r] && Ord<T>::finite(xv[r]);
-    s.x[e] = xv[r];
-    if (fin[r]) atomicMin(&s.pivot_at, e);
+    ok[r] = false;
+    fin[r] = false;
+    xv[r] = MinMax<T>::null_slot();
+    if (e < RK_CAP) {
+      uint32_t c = RK_SAT << 1;  // past-the-end slots sort after everything
+      if (e < len) {
+        uint64_t word = comp[rs + e];
+        uint64_t rel = (word >> low) - base;
+        ok[r] = (word & 1ull) != 0;
+        c = (uint32_t)(rel < RK_SAT ? rel : RK_SAT) << 1 | (ok[r] ? 1u : 0u);
+        if (ok[r]) {
+          xv[r] = xs[rs + e];
+          fin[r] = Ord<T>::finite(xv[r]);
+          if (fin[r]) atomicMin(&s.pivot_at, e);
+        }
+      }
+      s.ck[e] = c;
+      s.x[e] = xv[r];
+    }
   }
   __syncthreads();
   const int pat = s.pivot_at;
   const double pivot = pat < RK_CAP ? (double)s.x[pat] : 0.0;
 
-  // ---- inclusive prefixes over the extent, 512 elements per round
-  double carry_s = 0.0, carry_q = 0.0;
-  uint64_t carry_i = 0;
-  uint32_t carry_c = 0;
+  // ---- per 16-slot sub-block aggregates straight from registers (a sub-block = one DPP row)
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     int e = r * RK_THREADS + tid;
-    double d = fin[r] ? (double)xv[r] - pivot : 0.0;
-    double q = d * d;
-    uint64_t iv = (kInt && ok[r]) ? (uint64_t)xv[r] : 0ull;
-    uint32_t c = (ok[r] ? 1u : 0u) | ((ok[r] && !fin[r]) ? 0x10000u : 0u);
-    double is = d, iq = q;
-    uint64_t ii = iv;
-    uint32_t ic = c;
-    for (int off = 1; off < 64; off <<= 1) {
-      double ts_ = __shfl_up(is, off, 64), tq = __shfl_up(iq, off, 64);
-      uint32_t tc = __shfl_up(ic, off, 64);
-      if (lane >= off) { is += ts_; iq += tq; ic += tc; }
-      if (kInt) {
-        uint64_t ti = __shfl_up(ii, off, 64);
-        if (lane >= off) ii += ti;
+    if (e < RK_CAP) {  // uniform per wave: RK_CAP and RK_THREADS are multiples of 64
+      double d = fin[r] ? (double)xv[r] - pivot : 0.0;
+      double sd = row_sum_f64(d);
+      double sq = row_sum_f64(d * d);
+      uint32_t sc = row_sum_u32((ok[r] ? 1u : 0u) | ((ok[r] && !fin[r]) ? 0x10000u : 0u));
+      T vmn = ok[r] ? xv[r] : MinMax<T>::min_identity();
+      T vmx = ok[r] ? xv[r] : MinMax<T>::max_identity();
+      vmn = MinMax<T>::row_min(vmn);
+      vmx = MinMax<T>::row_max(vmx);
+      uint64_t si = 0;
+      if (kInt) si = row_sum_u64(ok[r] ? (uint64_t)xv[r] : 0ull);
+      if ((lane & 15) == 15) {
+        int b = e >> 4;
+        s.bs[b + 1] = sd;  // shifted by one: turned into exclusive prefixes below
+        s.bq[b + 1] = sq;
+        s.bc[b + 1] = sc;
+        if (kInt) s.bi[b + 1] = si;
+        s.mn[0][b] = vmn;
+        s.mx[0][b] = vmx;
       }
     }
-    if (lane == 63) { s.wave_s[wave] = is; s.wave_q[wave] = iq; s.wave_c[wave] = ic; s.wave_i[wave] = ii; }
-    __syncthreads();
-    double bs = carry_s, bq = carry_q;
-    uint64_t bi = carry_i;
-    uint32_t bc = carry_c;
-    double tot_s = 0.0, tot_q = 0.0;
-    uint64_t tot_i = 0;
-    uint32_t tot_c = 0;
-    for (int ww = 0; ww < RK_THREADS / 64; ++ww) {
-      if (ww < wave) { bs += s.wave_s[ww]; bq += s.wave_q[ww]; bc += s.wave_c[ww]; bi += s.wave_i[ww]; }
-      tot_s += s.wave_s[ww]; tot_q += s.wave_q[ww]; tot_c += s.wave_c[ww]; tot_i += s.wave_i[ww];
-    }
-    s.ps[e] = bs + is;
-    s.pq[e] = bq + iq;
-    s.pc[e] = bc + ic;
-    if (kInt) s.pi[e] = bi + ii;
-    carry_s += tot_s; carry_q += tot_q; carry_c += tot_c; carry_i += tot_i;
-    __syncthreads();
-  }
-
-  // ---- sparse table over 16-row sub-blocks (NULLs hold the identity of min / max)
-  for (int b = tid; b < RK_NSB; b += RK_THREADS) {
-    T mn = Ord<T>::min_id(), mx = Ord<T>::max_id();
-    bool any = false;
-    for (int k = 0; k < RK_SB; ++k) {
-      int e = b * RK_SB + k;
-      uint32_t c = s.pc[e] & 0xffffu, cp = e ? (s.pc[e - 1] & 0xffffu) : 0u;
-      if (c != cp) {
-        T v = s.x[e];
-        if (!any) { mn = v; mx = v; any = true; }
-        else {
-          if (Ord<T>::lt(v, mn)) mn = v;
-          if (Ord<T>::lt(mx, v)) mx = v;
-        }
-      }
-    }
-    s.mn[0][b] = mn;
-    s.mx[0][b] = mx;
   }
   __syncthreads();
-  for (int lv = 1; lv < RK_LEVELS; ++lv) {
-    int span = 1 << lv;
-    for (int b = tid; b + span <= RK_NSB; b += RK_THREADS) {
-      T a0 = s.mn[lv - 1][b], a1 = s.mn[lv - 1][b + span / 2];
-      s.mn[lv][b] = Ord<T>::lt(a1, a0) ? a1 : a0;
-      T b0 = s.mx[lv - 1][b], b1 = s.mx[lv - 1][b + span / 2];
-      s.mx[lv][b] = Ord<T>::lt(b0, b1) ? b1 : b0;
-    }
-    __syncthreads();
-  }
 
-  // ---- per-row frames
-  for (int64_t i = t0 + tid; i < t1; i += RK_THREADS) {
-    uint64_t cw = comp[i];
-    uint64_t k = cw >> low;
-    int64_t lo = lower_bound_k(comp, e0, i, frame_start_key(k, pmask, w), low);
-    int64_t hi = upper_bound_k(comp, i, e1 + 1, k, low) - 1;
-    o.perm[i] = (int32_t)perm[i];
-    int a = (int)(lo - e0), b = (int)(hi - e0);
-    uint32_t c1 = s.pc[b], c0 = a ? s.pc[a - 1] : 0u;
-    uint32_t dc = c1 - c0;
-    if (dc >> 16) {  // a non-finite value in the frame: exact sequential evaluation
-      rs_row_serial<T>(comp, xs, lo, hi, i, o);
-      continue;
+  // ---- wave 0: prefixes over the sub-blocks; waves 1 / 2: the sparse tables (wave-local work,
+  //      LDS keeps one wave's accesses in order)
+  if (wave == 0) {
+    constexpr int kEach = (RK_NSB + 63) / 64;
+    double vs[kEach], vq[kEach];
+    uint32_t vc[kEach];
+    uint64_t vi[kEach];
+    double ts_ = 0.0, tq = 0.0;
+    uint32_t tc = 0;
+    uint64_t ti = 0;
+#pragma unroll
+    for (int j = 0; j < kEach; ++j) {
+      int b = lane * kEach + j;
+      bool in = b < RK_NSB;
+      vs[j] = in ? s.bs[b + 1] : 0.0;
+      vq[j] = in ? s.bq[b + 1] : 0.0;
+      vc[j] = in ? s.bc[b + 1] : 0u;
+      vi[j] = (kInt && in) ? s.bi[b + 1] : 0ull;
+      ts_ += vs[j]; tq += vq[j]; tc += vc[j]; ti += vi[j];
     }
-    int64_t cnt = dc & 0xffffu;
-    double sd = s.ps[b] - (a ? s.ps[a - 1] : 0.0);
-    double sq = s.pq[b] - (a ? s.pq[a - 1] : 0.0);
-    // min / max over [a, b]: partial sub-blocks serially, whole sub-blocks from the table.
-    // NULL slots of s.x are skipped through the valid-count prefix.
-    T mn = Ord<T>::min_id(), mx = Ord<T>::max_id();
-    bool any = false;
-    int sa = a / RK_SB, sb = b / RK_SB;
-    int head_end = sa == sb ? b : (sa + 1) * RK_SB - 1;
+    double is = ts_, iq = tq;
+    uint32_t ic = tc;
+    uint64_t ii = ti;
+    for (int off = 1; off < 64; off <<= 1) {
+      double a = __shfl_up(is, off, 64), b = __shfl_up(iq, off, 64);
+      uint32_t c = __shfl_up(ic, off, 64);
+      uint64_t d = kInt ? __shfl_up(ii, off, 64) : 0ull;
+      if (lane >= off) { is += a; iq += b; ic += c; ii += d; }
+    }
+    double rs_ = is - ts_, rq = iq - tq;  // exclusive over lanes
+    uint32_t rc = ic - tc;
+    uint64_t ri = ii - ti;
+#pragma unroll
+    for (int j = 0; j < kEach; ++j) {
+      int b = lane * kEach + j;
+      if (b < RK_NSB) {
+        rs_ += vs[j]; rq += vq[j]; rc += vc[j]; ri += vi[j];
+        s.bs[b + 1] = rs_;
+        s.bq[b + 1] = rq;
+        s.bc[b + 1] = rc;
+        if (kInt) s.bi[b + 1] = ri;
+      }
+    }
+    if (lane == 0) {
+      s.bs[0] = 0.0; s.bq[0] = 0.0; s.bc[0] = 0u;
+      if (kInt) s.bi[0] = 0ull;
+    }
+  } else if (wave == 1 || wave == 2) {
+    volatile T *tab = wave == 1 ? &s.mn[0][0] : &s.mx[0][0];
+    for (int lv = 1; lv < RK_LEVELS; ++lv) {
+      int span = 1 << lv;
+      for (int b = lane; b + span <= RK_NSB; b += 64) {
+        T a0 = tab[(lv - 1) * RK_NSB + b], a1 = tab[(lv - 1) * RK_NSB + b + span / 2];
+        tab[lv * RK_NSB + b] = wave == 1 ? MinMax<T>::mn(a0, a1) : MinMax<T>::mx(a0, a1);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+
+  // ---- one output row per thread
+  const int64_t i = t0 + tid;
+  if (i >= t1) return;
+  const int li = (int)(i - rs);
+  const uint32_t cki = s.ck[li];
+  const uint64_t k = comp[i] >> low;
+  const uint64_t kstart = frame_start_key(k, pmask, w);
+  const uint32_t krel = cki >> 1;
+  const uint64_t srel64 = kstart > base ? kstart - base : 0;
+  const uint32_t srel = (uint32_t)(srel64 < RK_SAT ? srel64 : RK_SAT);
+  int a, b;
+  {
+    int lo = 0, hi = li;  // first slot in [0, li] at or after the frame start
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if ((s.ck[mid] >> 1) < srel) lo = mid + 1;
+      else hi = mid;
+    }
+    a = lo;
+    // last slot of the row's own second: gallop forward (usually the row itself or close)
+    int step = 1;
+    lo = li + 1;
+    hi = li + 1;
+    while (hi < len && (s.ck[hi] >> 1) <= krel) { lo = hi + 1; hi += step; step <<= 1; }
+    if (hi > len) hi = len;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if ((s.ck[mid] >> 1) <= krel) lo = mid + 1;
+      else hi = mid;
+    }
+    b = lo - 1;
+  }
+  o.perm[i] = (int32_t)perm[i];
+  const bool open_left = a == 0 && rs > 0;          // the frame may start before the region
+  const bool open_right = b == len - 1 && re < n;   // peers may continue after the region
+  bool slow = open_left || open_right || krel >= RK_SAT;
+
+  // head / tail sub-blocks slot by slot, whole sub-blocks from the prefixes and tables
+  double sd = 0.0, sq = 0.0;
+  uint32_t dc = 0;
+  uint64_t isum = 0;
+  T mn = MinMax<T>::min_identity(), mx = MinMax<T>::max_identity();
+  const int sa = a / RK_SB, sb = b / RK_SB;
+  if (!slow) {
+    const int head_end = sa == sb ? b : (sa + 1) * RK_SB - 1;
     for (int e = a; e <= head_end; ++e) {
-      uint32_t c = s.pc[e] & 0xffffu, cp = e ? (s.pc[e - 1] & 0xffffu) : 0u;
-      if (c != cp) {
+      if (s.ck[e] & 1u) {
         T v = s.x[e];
-        if (!any) { mn = v; mx = v; any = true; }
-        else {
-          if (Ord<T>::lt(v, mn)) mn = v;
-          if (Ord<T>::lt(mx, v)) mx = v;
+        if (Ord<T>::finite(v)) {
+          double d = (double)v - pivot;
+          sd += d;
+          sq += d * d;
+          ++dc;
+          if (kInt) isum += (uint64_t)v;
+          mn = MinMax<T>::mn(mn, v);
+          mx = MinMax<T>::mx(mx, v);
+        } else {
+          dc += 0x10000u;
         }
       }
     }
     if (sa != sb) {
       for (int e = sb * RK_SB; e <= b; ++e) {
-        uint32_t c = s.pc[e] & 0xffffu, cp = e ? (s.pc[e - 1] & 0xffffu) : 0u;
-        if (c != cp) {
+        if (s.ck[e] & 1u) {
           T v = s.x[e];
-          if (!any) { mn = v; mx = v; any = true; }
-          else {
-            if (Ord<T>::lt(v, mn)) mn = v;
-            if (Ord<T>::lt(mx, v)) mx = v;
+          if (Ord<T>::finite(v)) {
+            double d = (double)v - pivot;
+            sd += d;
+            sq += d * d;
+            ++dc;
+            if (kInt) isum += (uint64_t)v;
+            mn = MinMax<T>::mn(mn, v);
+            mx = MinMax<T>::mx(mx, v);
+          } else {
+            dc += 0x10000u;
           }
         }
       }
-      int m0 = sa + 1, m1 = sb - 1;
+      const int m0 = sa + 1, m1 = sb - 1;
       if (m0 <= m1) {
-        // whole sub-blocks: valid counts tell whether they hold any value at all
-        uint32_t cm = (s.pc[(m1 + 1) * RK_SB - 1] & 0xffffu) - (s.pc[m0 * RK_SB - 1] & 0xffffu);
-        if (cm) {
-          int lv = 31 - __clz(m1 - m0 + 1);
-          T a0 = s.mn[lv][m0], a1 = s.mn[lv][m1 + 1 - (1 << lv)];
-          T tmn = Ord<T>::lt(a1, a0) ? a1 : a0;
-          T b0 = s.mx[lv][m0], b1 = s.mx[lv][m1 + 1 - (1 << lv)];
-          T tmx = Ord<T>::lt(b0, b1) ? b1 : b0;
-          if (!any) { mn = tmn; mx = tmx; any = true; }
-          else {
-            if (Ord<T>::lt(tmn, mn)) mn = tmn;
-            if (Ord<T>::lt(mx, tmx)) mx = tmx;
-          }
-        }
+        sd += s.bs[m1 + 1] - s.bs[m0];
+        sq += s.bq[m1 + 1] - s.bq[m0];
+        dc += s.bc[m1 + 1] - s.bc[m0];
+        if (kInt) isum += s.bi[m1 + 1] - s.bi[m0];
+        const int lv = 31 - __clz(m1 - m0 + 1);
+        mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.mn[lv][m0], s.mn[lv][m1 + 1 - (1 << lv)]));
+        mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.mx[lv][m0], s.mx[lv][m1 + 1 - (1 << lv)]));
       }
     }
-    double nd = (double)cnt;
-    double mean = cnt ? pivot + sd / nd : 0.0;
-    T sum;
-    if constexpr (kInt) sum = (T)(s.pi[b] - (a ? s.pi[a - 1] : 0ull));
-    else sum = (T)(nd * pivot + sd);
-    double stddev = 0.0;
-    if (cnt > 1) {
-      bool same = !Ord<T>::lt(mn, mx) && !Ord<T>::lt(mx, mn);  // all values identical: m2 is exactly 0
-      double m2 = same ? 0.0 : sq - sd * sd / nd;
-      // The prefix difference carries an absolute error of a few ulps of the running total.
-      // When the frame's spread is tiny against that total, redo it as a corrected two-pass
-      // sum around the frame mean (rare: near-constant frames inside a varying extent).
-      if (!same && m2 < 1e-5 * s.pq[b]) {
-        double acc = 0.0, lin = 0.0;
-        for (int e = a; e <= b; ++e) {
-          uint32_t c = s.pc[e] & 0xffffu, cp = e ? (s.pc[e - 1] & 0xffffu) : 0u;
-          if (c != cp) {
-            double dv = (double)s.x[e] - mean;
-            acc += dv * dv;
-            lin += dv;
-          }
-        }
-        m2 = acc - lin * lin / nd;
-      }
-      if (m2 < 0.0) m2 = 0.0;
-      stddev = sqrt(m2 / (nd - 1.0));
-    }
-    rs_store<T>(o, i, cnt, mean, mn, mx, sum, cnt > 1, stddev, (cw & 1ull) != 0, (double)s.x[i - e0]);
+    slow = (dc >> 16) != 0;  // a non-finite value inside the frame
   }
+  if (slow) {
+    // exact sequential evaluation from global memory (Spark's own recurrence)
+    int64_t glo = rs + a, ghi = rs + b;
+    if (open_left || krel >= RK_SAT) glo = lower_bound_k(comp, 0, i, kstart, low);
+    if (open_right || krel >= RK_SAT) ghi = upper_bound_k(comp, i, n, k, low) - 1;
+    rs_row_serial<T>(comp, xs, glo, ghi, i, o);
+    return;
+  }
+  const int64_t cnt = dc & 0xffffu;
+  const double nd = (double)cnt;
+  const double mean = cnt ? pivot + sd / nd : 0.0;
+  T sum;
+  if constexpr (kInt) sum = (T)isum;
+  else sum = (T)(nd * pivot + sd);
+  double stddev = 0.0;
+  if (cnt > 1) {
+    const bool same = mn == mx;  // all values identical: Spark's m2 is exactly 0
+    double m2 = same ? 0.0 : sq - sd * sd / nd;
+    // The prefix difference carries an absolute error of a few ulps of the running total.
+    // When the frame's spread is tiny against that total, redo it as a corrected two-pass
+    // sum around the frame mean (rare: near-constant frames inside a varying region).
+    if (!same && m2 < 1e-5 * (s.bq[sb] + sq)) {
+      double acc = 0.0, lin = 0.0;
+      for (int e = a; e <= b; ++e) {
+        if (s.ck[e] & 1u) {
+          double dv = (double)s.x[e] - mean;
+          acc += dv * dv;
+          lin += dv;
+        }
+      }
+      m2 = acc - lin * lin / nd;
+    }
+    if (m2 < 0.0) m2 = 0.0;
+    stddev = sqrt(m2 / (nd - 1.0));
+  }
+  rs_store<T>(o, i, cnt, mean, mn, mx, sum, cnt > 1, stddev, (cki & 1u) != 0, (double)s.x[li]);
 }
 
 template <typename T>
@@ -413,7 +543,7 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   OrderResult res;
   bool sorted = r.unsorted == 0;
-  TMP_TRY(order_build(s, lay, sorted, p.ob, &res, st));
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st));
   const T *xs = (const T *)a->x;
   if (!sorted) {
     TMP_LAUNCH(gather_sorted_kernel<T>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock), st, (const T *)a->x, res.perm, a->n, (T *)p.xs);

@@ -60,7 +60,8 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
 
     Returns (row_idx[nL], mask_idx[n_masks, nL], missing[1 + n_masks]) as int32 device tensors:
     the right row each left row takes its values from (last visible row / last visible row
-    whose mask is valid), -1 for none.
+    whose mask is valid), -1 for none.  row_idx and mask_idx are strided views of one
+    [nL, 1 + n_masks] record array (gather() accepts them as they are).
     """
     nL, nR = ts_l.numel(), ts_r.numel()
     dev = ts_l.device
@@ -75,8 +76,7 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
         raise NotImplementedError(f"at most {_lib.TMP_MAX_MASKS} nullable right columns per call")
     for i, m in enumerate(masks):
         _dev(m, torch.uint8, f"masks[{i}]", nR)
-    row_idx = torch.empty(nL, dtype=torch.int32, device=dev)
-    mask_idx = torch.empty((len(masks), nL), dtype=torch.int32, device=dev)
+    idx = torch.empty((nL, 1 + len(masks)), dtype=torch.int32, device=dev)
     missing = torch.empty(1 + len(masks), dtype=torch.int32, device=dev)
     skew = ts_partition_val is not None
     a = AsofArgs()
@@ -90,16 +90,20 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
     a.v_is_int = int(skew and isinstance(ts_partition_val, int))
     a.ts_partition_val = float(ts_partition_val) if skew else 0.0
     a.one_minus_fraction = float(1 - fraction)  # evaluated in Python float as tsdf.py:185
-    a.out_row_idx, a.out_mask_idx, a.out_missing = _p(row_idx), _p(mask_idx), _p(missing)
+    a.out_idx, a.out_missing = _p(idx), _p(missing)
     ws = _workspace(lib().tmp_asof_join_workspace_bytes(C.byref(a)), dev)
     check(lib().tmp_asof_join(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_asof_join")
-    return row_idx, mask_idx, missing
+    return idx[:, 0], idx[:, 1:].t(), missing
 
 
 def gather(src, idx, src_valid=None, want_valid=True):
     """out[i] = src[idx[i]] (0 / invalid where idx[i] < 0 or the source is NULL)."""
     n = idx.numel()
-    _dev(idx, torch.int32, "idx")
+    if not isinstance(idx, torch.Tensor) or not idx.is_cuda or idx.dtype != torch.int32 or idx.dim() != 1:
+        raise TypeError("idx must be a 1-D int32 CUDA (ROCm) tensor; tempo_amd has no CPU path")
+    idx_stride = idx.stride(0) if n > 1 else 1
+    if idx_stride < 1:
+        raise ValueError("idx must have a positive stride")
     if not src.is_cuda or src.dim() != 1 or not src.is_contiguous():
         raise ValueError("src must be a contiguous 1-D CUDA tensor")
     if src.element_size() not in (1, 4, 8):
@@ -107,7 +111,7 @@ def gather(src, idx, src_valid=None, want_valid=True):
     _dev(src_valid, torch.uint8, "src_valid", src.numel())
     out = torch.empty(n, dtype=src.dtype, device=src.device)
     out_valid = torch.empty(n, dtype=torch.uint8, device=src.device) if want_valid else None
-    check(lib().tmp_gather(_p(src), _p(src_valid), src.element_size(), _p(idx), n, _p(out),
+    check(lib().tmp_gather(_p(src), _p(src_valid), src.element_size(), _p(idx), idx_stride, n, _p(out),
                            _p(out_valid), _stream()), "tmp_gather")
     return out, out_valid
 

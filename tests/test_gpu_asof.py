@@ -143,3 +143,21 @@ def test_gather(ops):
     ok = (idx >= 0) & (valid[np.clip(idx, 0, None)] == 1)
     assert np.array_equal(ov.cpu().numpy().astype(bool), ok)
     assert np.array_equal(out.cpu().numpy(), np.where(ok, src[np.clip(idx, 0, None)], 0.0))
+
+
+@pytest.mark.parametrize("with_seq", [False, True])
+def test_asof_time_ordered_feeds(orc, ops, with_seq):
+    """Both tables in arrival (time) order with interleaved keys: key-only radix passes."""
+    rng = np.random.default_rng(21)
+    key_l, ts_l, key_r, ts_r, seq, seq_valid, masks = _make(rng, 150_000, 120_000, 64, 3600 * 1_000_000, 1000, 2,
+                                                            0.05, with_seq)
+    o = np.argsort(ts_l, kind="stable"); key_l, ts_l = key_l[o], ts_l[o]
+    if with_seq:  # arrival order = (ts, seq NULLS FIRST)
+        o = np.lexsort((np.where(seq_valid == 1, seq, -10**9), ts_r))
+    else:
+        o = np.argsort(ts_r, kind="stable")
+    key_r, ts_r = key_r[o], ts_r[o]
+    masks = [m[o] for m in masks]
+    if with_seq:
+        seq, seq_valid = seq[o], seq_valid[o]
+    _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, seq, seq_valid, masks), 64)

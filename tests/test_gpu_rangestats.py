@@ -133,3 +133,11 @@ def test_range_stats_golden(ops, golden):
         else:
             assert abs(g["stddev"][p] - e["stddev_trade_pr"]) < 0.00501
             assert abs(g["zscore"][p] - e["zscore_trade_pr"]) < 0.00501
+
+
+def test_range_stats_time_ordered_feed(orc, ops):
+    """Rows in time order with interleaved keys (a live feed): only the key bits need sorting."""
+    rng = np.random.default_rng(15)
+    key, ts, x, xv = _ticks(rng, 80_000, 12, 1.0, 0.01, sort=True)  # sort=True keeps arrival order
+    assert (np.diff(ts) >= 0).all() and (np.diff(key) < 0).any()
+    _compare(orc, ops, key, ts, x, xv, 12, 600)

@@ -157,3 +157,15 @@ def test_hash_partition_matches_host_owner(ops):
     owner = np.array([_lib.lib().tmp_key_owner(int(k), parts) for k in range(5000)])[key]
     assert np.array_equal(counts, np.bincount(owner, minlength=parts))
     assert np.array_equal(perm, np.argsort(owner, kind="stable"))
+
+
+def test_ema_time_ordered_feed(orc, ops):
+    rng = np.random.default_rng(31)
+    n = 60_000
+    key = rng.integers(0, 9, n).astype(np.int32)
+    ts = BASE + np.sort(rng.integers(0, 500_000, n)) * 5_000
+    x = rng.normal(0, 1, n)
+    perm, out = ops.ema(_dev(key), _dev(ts), _dev(x), None, 9, window=30)
+    operm, oout = orc.ema(key, ts, x, None, 30, 0.2)
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), operm)
+    assert np.array_equal(out.cpu().numpy(), oout)
