@@ -4,8 +4,8 @@
 One step = one pass of the hot path over one batch of device-resident synthetic input:
   1. asofJoin of `rows/2` trades against `rows/2` quotes (10 000 Zipf(1.2) symbols, uniform
      microsecond timestamps over one trading day, skew mode tsPartitionVal=10 fraction=0.1,
-     three joined right columns, two of them with 1 % NULLs), including the gather that
-     materialises the joined columns;
+     three joined right columns, two of them with 1 % NULLs), including the gathers that
+     materialise the joined table (left payload + three right columns) in (key, ts) order;
   2. withRangeStats(rangeBackWindowSecs=600) of one fp64 metric over `rows` ticks
      (100 symbols, Exp(1 s) inter-arrival per symbol, 0.5 % NULLs).
 value = rows consumed by both operators (2 x rows) / step time, inputs already in HBM.
@@ -51,6 +51,7 @@ def gen_trades_quotes(dev, n_left, n_right, n_keys, seed):
     d = {}
     d["key_l"] = zipf(n_left)
     d["ts_l"] = BASE_US + torch.randint(0, DAY_US, (n_left,), generator=g, device=dev, dtype=torch.int64)
+    d["trade_pr"] = 100.0 + torch.randn(n_left, generator=g, device=dev, dtype=torch.float64)
     d["key_r"] = zipf(n_right)
     d["ts_r"] = BASE_US + torch.randint(0, DAY_US, (n_right,), generator=g, device=dev, dtype=torch.int64)
     d["bid"] = 100.0 + torch.randn(n_right, generator=g, device=dev, dtype=torch.float64)
@@ -135,21 +136,25 @@ def main():
         if world > 1:
             # Exchange hashpartitioning(key): bucket on device, one all-to-all per column
             _lib.profile_tag(0)
-            kl, (tl,), _, _ = shuffle_by_key(tq["key_l"], [tq["ts_l"]])
+            kl, (tl, pr), _, _ = shuffle_by_key(tq["key_l"], [tq["ts_l"], tq["trade_pr"]])
             kr, (tr, bid, ask, bv, av), _, _ = shuffle_by_key(
                 tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]])
-            q = dict(key_l=kl, ts_l=tl, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
+            q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
             kk, (tt, xx, xv), _, _ = shuffle_by_key(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
             t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
         _lib.profile_tag(1)
-        row, midx, missing = ops.asof_join(q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS,
-                                           masks=[q["bid_valid"], q["ask_valid"]],
-                                           ts_partition_val=10, fraction=0.1)
+        # joined table in (key, ts) order, as Spark's window leaves it: key / ts come back
+        # ordered, the left payload is gathered through perm, the right columns through the
+        # match indices
+        row, midx, missing, perm, key_s, ts_s = ops.asof_join(
+            q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, masks=[q["bid_valid"], q["ask_valid"]],
+            ts_partition_val=10, fraction=0.1, sorted_output=True)
+        l_pr, _ = ops.gather(q["trade_pr"], perm, want_valid=False)
         r_ts, _ = ops.gather(q["ts_r"], row)
         r_bid, _ = ops.gather(q["bid"], midx[0])
         r_ask, _ = ops.gather(q["ask"], midx[1])
         n1 = q["ts_l"].numel() + q["ts_r"].numel()
-        del row, midx, r_ts, r_bid, r_ask
+        del row, midx, perm, key_s, ts_s, l_pr, r_ts, r_bid, r_ask
         _lib.profile_tag(2)
         out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
         n2 = t["ts"].numel()

@@ -88,6 +88,12 @@ int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t workspace_byt
  * tsdf.py:178-185 (ts_partition_val = tsPartitionVal, v_is_int = it was a Python int,
  * one_minus_fraction = 1 - fraction computed by the caller in double).
  * masks: HOST array of n_masks device pointers (<= TMP_MAX_MASKS).
+ * Row order of the result: sorted_output == 0 keeps the left table's own row order (record i
+ * belongs to left row i; costs one random 4*(1+n_masks)-byte write per row).  sorted_output != 0
+ * returns records in (key, ts) order -- the order Spark's window leaves them in, and the order
+ * every later window operator wants: record p belongs to left row out_perm[p]; out_key /
+ * out_ts (optional) receive that row's key id and timestamp, so only the left payload columns
+ * have to be gathered through out_perm.
  */
 #define TMP_MAX_MASKS 16
 
@@ -109,6 +115,10 @@ typedef struct {
   double ts_partition_val;
   double one_minus_fraction;
   int32_t *out_idx;      /* [n_left][1 + n_masks] */
+  int32_t sorted_output;
+  int32_t *out_perm;     /* [n_left], required when sorted_output != 0 */
+  int32_t *out_key;      /* [n_left] or NULL (sorted_output only) */
+  int64_t *out_ts;       /* [n_left] or NULL (sorted_output only) */
   int32_t *out_missing;  /* [1 + n_masks] */
 } tmp_asof_args;
 

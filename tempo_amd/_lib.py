@@ -29,7 +29,8 @@ class AsofArgs(C.Structure):
                 ("seq_right_valid", _vp), ("n_keys", C.c_int32), ("ts_is_seconds", C.c_int32),
                 ("n_masks", C.c_int32), ("masks", C.POINTER(_vp)), ("skew", C.c_int32),
                 ("v_is_int", C.c_int32), ("ts_partition_val", C.c_double),
-                ("one_minus_fraction", C.c_double), ("out_idx", _vp), ("out_missing", _vp)]
+                ("one_minus_fraction", C.c_double), ("out_idx", _vp), ("sorted_output", C.c_int32),
+                ("out_perm", _vp), ("out_key", _vp), ("out_ts", _vp), ("out_missing", _vp)]
 
 
 class RangeStatsArgs(C.Structure):

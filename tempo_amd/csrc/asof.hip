@@ -195,13 +195,24 @@ __device__ __forceinline__ int64_t upper_bound(const uint64_t *comp, int64_t lo,
   return lo;
 }
 
-constexpr int kMergeRows = 4;  // left rows per thread
+// id of right position j, reusing the id already fetched for the row rule when it is valid
+__device__ __forceinline__ int32_t row_src_or(const uint32_t *perm_r, int32_t j, int32_t row_src) {
+  return row_src >= 0 ? row_src : (int32_t)perm_r[j];
+}
 
+constexpr int kMergeRows = 4;     // left rows per thread
+constexpr int kMergeRight = 3072;  // right sort words staged in LDS per block
+
+// Block = 1024 consecutive rows of the ordered left side.  Their positions in the ordered right
+// side all fall between the positions of the block's first and last row; that slice of right
+// sort words is staged in LDS (when it fits) and every row binary-searches it there.
 __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
-    SkewParams sp, int32_t *out_idx, int32_t *out_missing) {
+    SkewParams sp, int32_t *out_idx, int32_t *out_missing, int sorted_output, int32_t *out_perm,
+    int32_t *out_key, int64_t *out_ts) {
   __shared__ int64_t bounds[2];
+  __shared__ uint64_t rw[kMergeRight];
   const int low = lay.low_bits;
   int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
   int64_t tile_end = tile + kBlock * kMergeRows < n_left ? tile + kBlock * kMergeRows : n_left;
@@ -216,6 +227,11 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
   }
   __syncthreads();
   const int64_t blo = bounds[0], bhi = bounds[1];
+  const bool staged = bhi - blo <= kMergeRight;  // block-uniform
+  if (staged) {
+    for (int e = threadIdx.x; e < (int)(bhi - blo); e += kBlock) rw[e] = comp_r[blo + e];
+    __syncthreads();
+  }
   int miss_row = 0;
   uint32_t miss_mask = 0;
   for (int r = 0; r < kMergeRows; ++r) {
@@ -223,15 +239,35 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     if (i >= tile_end) break;
     uint64_t wl = comp_l[i];
     uint64_t kl = wl >> low;
-    int64_t pos = upper_bound(comp_r, blo, bhi, kl, low);
+    int64_t pos;
+    uint64_t wr_row = 0;
+    if (staged) {
+      int lo = 0, hi = (int)(bhi - blo);
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((rw[mid] >> low) <= kl) lo = mid + 1;
+        else hi = mid;
+      }
+      pos = blo + lo;
+      if (lo > 0) wr_row = rw[lo - 1];
+    } else {
+      pos = upper_bound(comp_r, blo, bhi, kl, low);
+      if (pos > blo) wr_row = comp_r[pos - 1];
+    }
     int64_t jr = pos - 1;
     uint32_t key_l = lay.key_of(wl);
-    bool same = jr >= 0 && lay.key_of(comp_r[jr]) == key_l;
+    bool same = jr >= blo && lay.key_of(wr_row) == key_l;
     double part_l = 0.0, rem_l;
     if (sp.enabled) bracket_of(lay.prim_of(wl), sp, &part_l, &rem_l);
-    uint32_t dst = perm_l[i];
+    uint32_t src_row = perm_l[i];
+    uint32_t dst = sorted_output ? (uint32_t)i : src_row;
+    if (sorted_output) {
+      out_perm[i] = (int32_t)src_row;
+      if (out_key) out_key[i] = (int32_t)key_l;
+      if (out_ts) out_ts[i] = lay.prim_of(wl);
+    }
     int32_t row_src = -1;
-    if (same && (!sp.enabled || bracket_visible(lay.prim_of(comp_r[jr]), part_l, sp)))
+    if (same && (!sp.enabled || bracket_visible(lay.prim_of(wr_row), part_l, sp)))
       row_src = (int32_t)perm_r[jr];
     int32_t *rec = out_idx + (size_t)dst * (1 + n_masks);
     rec[0] = row_src;
@@ -241,10 +277,10 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       if (same) {
         int32_t j = lastnn[(size_t)m * n_right + jr];
         if (j >= 0) {
-          uint64_t wr = comp_r[j];
+          uint64_t wr = (staged && j >= blo) ? rw[j - blo] : comp_r[j];
           if (lay.key_of(wr) == key_l &&
               (!sp.enabled || bracket_visible(lay.prim_of(wr), part_l, sp)))
-            src = (int32_t)perm_r[j];
+            src = j == jr ? row_src_or(perm_r, j, row_src) : (int32_t)perm_r[j];
         }
       }
       rec[1 + m] = src;
@@ -288,6 +324,8 @@ static int asof_validate(const tmp_asof_args *a) {
   TMP_REQUIRE(a->n_right == 0 || a->ts_right, TMP_EINVAL, "tmp_asof_join: ts_right is null");
   TMP_REQUIRE(a->n_masks == 0 || a->masks, TMP_EINVAL, "tmp_asof_join: masks missing");
   TMP_REQUIRE(a->n_left == 0 || a->out_idx, TMP_EINVAL, "tmp_asof_join: out_idx is null");
+  TMP_REQUIRE(a->n_left == 0 || !a->sorted_output || a->out_perm, TMP_EINVAL,
+              "tmp_asof_join: out_perm is required with sorted_output");
   TMP_REQUIRE(a->out_missing, TMP_EINVAL, "tmp_asof_join: out_missing is null");
   if (a->skew) {
     TMP_REQUIRE(a->ts_partition_val == a->ts_partition_val && a->ts_partition_val != 0.0, TMP_EINVAL,
@@ -316,7 +354,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   asof_plan(a, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE,
               "tmp_asof_join: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
-  if (a->n_right == 0) {  // nothing to match: every index is -1, everything is missing
+  if (a->n_right == 0 && !a->sorted_output) {  // nothing to match: every index is -1, everything is missing
     int grid = grid_for(a->n_left, kBlock * 4, 8192);
     TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_idx, a->n_left * (1 + a->n_masks), -1);
     TMP_LAUNCH(fill_i32_kernel, dim3(1), dim3(64), st, a->out_missing, 1 + a->n_masks, 1);
@@ -343,7 +381,9 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   both.prim_min = rl.prim_min < rr.prim_min ? rl.prim_min : rr.prim_min;
   both.prim_max = rl.prim_max > rr.prim_max ? rl.prim_max : rr.prim_max;
   Layout lay;
-  TMP_TRY(order_make_layout(rs, both, a->n_masks, &lay));
+  OrderSpec lay_spec = rs;  // the key field exists if either side carries keys (one may be empty)
+  if (!lay_spec.key) lay_spec.key = ls.key;
+  TMP_TRY(order_make_layout(lay_spec, both, a->n_masks, &lay));
   OrderResult lo, ro;
   TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
   TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
@@ -366,7 +406,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
                      ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                     a->out_missing);
+                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

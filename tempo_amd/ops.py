@@ -55,13 +55,16 @@ def sort_order(key, ts, n_keys, floor_seconds=False, seq=None, seq_valid=None):
 
 
 def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, masks=(),
-              ts_is_seconds=False, ts_partition_val=None, fraction=0.5):
+              ts_is_seconds=False, ts_partition_val=None, fraction=0.5, sorted_output=False):
     """AS-OF match (python/tempo/tsdf.py:463-560).
 
     Returns (row_idx[nL], mask_idx[n_masks, nL], missing[1 + n_masks]) as int32 device tensors:
     the right row each left row takes its values from (last visible row / last visible row
     whose mask is valid), -1 for none.  row_idx and mask_idx are strided views of one
     [nL, 1 + n_masks] record array (gather() accepts them as they are).
+
+    sorted_output=True returns the records in (key, ts) order instead of the left table's row
+    order, followed by (perm, key_sorted, ts_sorted): record p belongs to left row perm[p].
     """
     nL, nR = ts_l.numel(), ts_r.numel()
     dev = ts_l.device
@@ -91,8 +94,16 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
     a.ts_partition_val = float(ts_partition_val) if skew else 0.0
     a.one_minus_fraction = float(1 - fraction)  # evaluated in Python float as tsdf.py:185
     a.out_idx, a.out_missing = _p(idx), _p(missing)
+    perm = key_s = ts_s = None
+    if sorted_output:
+        perm = torch.empty(nL, dtype=torch.int32, device=dev)
+        key_s = torch.empty(nL, dtype=torch.int32, device=dev)
+        ts_s = torch.empty(nL, dtype=torch.int64, device=dev)
+        a.sorted_output, a.out_perm, a.out_key, a.out_ts = 1, _p(perm), _p(key_s), _p(ts_s)
     ws = _workspace(lib().tmp_asof_join_workspace_bytes(C.byref(a)), dev)
     check(lib().tmp_asof_join(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_asof_join")
+    if sorted_output:
+        return idx[:, 0], idx[:, 1:].t(), missing, perm, key_s, ts_s
     return idx[:, 0], idx[:, 1:].t(), missing
 
 

@@ -161,3 +161,24 @@ def test_asof_time_ordered_feeds(orc, ops, with_seq):
     if with_seq:
         seq, seq_valid = seq[o], seq_valid[o]
     _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, seq, seq_valid, masks), 64)
+
+
+def test_asof_sorted_output_mode(orc, ops):
+    """sorted_output: the same matches, delivered in (key, ts) order with the row permutation."""
+    rng = np.random.default_rng(33)
+    key_l, ts_l, key_r, ts_r, _, _, masks = _make(rng, 70_000, 50_000, 17, 900 * 1_000_000, 1000, 2, 0.1, False)
+    row, midx, missing, perm, key_s, ts_s = ops.asof_join(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), 17,
+                                                          masks=[_dev(m) for m in masks], sorted_output=True)
+    idx, omiss = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None] + masks)
+    p = perm.cpu().numpy().astype(np.int64)
+    assert np.array_equal(p, np.lexsort((np.arange(len(ts_l)), ts_l, key_l)))  # stable (key, ts) order
+    assert np.array_equal(key_s.cpu().numpy(), key_l[p]) and np.array_equal(ts_s.cpu().numpy(), ts_l[p])
+    assert np.array_equal(row.cpu().numpy(), idx[0][p])
+    for m in range(2):
+        assert np.array_equal(midx[m].cpu().numpy(), idx[1 + m][p])
+    assert missing.cpu().numpy().tolist() == omiss.tolist()
+    # an empty right side still orders the left side
+    row, midx, missing, perm, key_s, ts_s = ops.asof_join(_dev(key_l), _dev(ts_l), _dev(key_r[:0]), _dev(ts_r[:0]),
+                                                          17, sorted_output=True)
+    assert (row.cpu().numpy() == -1).all() and np.array_equal(perm.cpu().numpy().astype(np.int64), p)
+    assert missing.cpu().numpy().tolist() == [1]
