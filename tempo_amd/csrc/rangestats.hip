@@ -22,9 +22,9 @@ constexpr int RK_ROWS = 1024;
 constexpr int RK_CAP = 2560;
 constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
-constexpr int RK_SB = 16;
-constexpr int RK_NSB = RK_CAP / RK_SB;  // 160
-constexpr int RK_LEVELS = 8;            // 2^7 < 160 <= 2^8
+constexpr int RK_SB = 8;                 // slots per sub-block (half a DPP row)
+constexpr int RK_NSB = RK_CAP / RK_SB;  // 320
+constexpr int RK_LEVELS = 8;            // spans up to 128 sub-blocks; longer runs use three spans
 
 template <typename T>
 struct Ord;
@@ -135,7 +135,8 @@ __device__ __forceinline__ uint64_t frame_start_key(uint64_t k, uint64_t prim_ma
   return (k - rel) + (rel > w ? rel - w : 0);
 }
 
-// ---- 16-lane (one DPP row) inclusive scans: lane 15 of every row ends up with the row total.
+// ---- 8-lane inclusive scans inside a DPP row (row_shr 1, 2, 4): lanes 7 and 15 of every row
+//      end up with the totals of their 8-lane halves.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int old, int v, bool bound_zero) {
   return bound_zero ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true)
@@ -155,9 +156,8 @@ __device__ __forceinline__ uint64_t dpp_u64(uint64_t v, bool bound_zero) {
   hi = dpp_i32<CTRL>(hi, hi, bound_zero);
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
-// row_shr:1/2/4/8 = 0x111 / 0x112 / 0x114 / 0x118
-#define TMP_ROW_SCAN(expr_shr)  \
-  expr_shr(0x111) expr_shr(0x112) expr_shr(0x114) expr_shr(0x118)
+// row_shr:1/2/4 = 0x111 / 0x112 / 0x114
+#define TMP_ROW_SCAN(expr_shr) expr_shr(0x111) expr_shr(0x112) expr_shr(0x114)
 
 __device__ __forceinline__ double row_sum_f64(double v) {
 #define S_(c) v += dpp_f64<c>(v, true);
@@ -226,6 +226,35 @@ struct MinMax<int64_t> {
 
 constexpr uint32_t RK_SAT = 0x7fffffffu;  // saturated relative sort word
 
+// 1/a and sqrt(a) from the hardware approximations plus one Newton step each: a few ulps, far
+// inside the 1e-9 the statistics are held to, at a fraction of the IEEE expansions' cost.
+__device__ __forceinline__ double fast_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  return __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_sqrt(double a) {
+  if (!(a > 0.0)) return 0.0;
+  double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, a);  // residual a - g^2
+  return __builtin_fma(d, h, g);
+}
+
+// One staged slot of a double metric into the frame's running sums; NULL slots hold NaN.
+__device__ __forceinline__ void slot_add_f64(double v, double pivot, double &sd, double &sq, uint32_t &dc,
+                                             double &mn, double &mx) {
+  bool okv = v == v;
+  double d = okv ? v - pivot : 0.0;
+  sd += d;
+  sq += d * d;
+  dc += okv ? 1u : 0u;
+  mn = fmin(mn, v);
+  mx = fmax(mx, v);
+}
+
 template <typename T>
 struct RsShared {
   static constexpr bool kIntT = ((T)0.5 == (T)0);
@@ -238,6 +267,7 @@ struct RsShared {
   T mn[RK_LEVELS][RK_NSB];   // sparse tables over sub-block minima / maxima
   T mx[RK_LEVELS][RK_NSB];
   int pivot_at;
+  int nonfinite;  // some staged value is NaN or +-inf
 };
 
 template <typename T>
@@ -259,7 +289,7 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   const int64_t re = t0 + RK_ROWS + RK_FWD < n ? t0 + RK_ROWS + RK_FWD : n;
   const int len = (int)(re - rs);
   const uint64_t base = comp[rs] >> low;
-  if (tid == 0) s.pivot_at = RK_CAP;
+  if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; }
   __syncthreads();
 
   // ---- stage the region: one coalesced read of sort words and metric values
@@ -283,6 +313,7 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
           xv[r] = xs[rs + e];
           fin[r] = Ord<T>::finite(xv[r]);
           if (fin[r]) atomicMin(&s.pivot_at, e);
+          else s.nonfinite = 1;
         }
       }
       s.ck[e] = c;
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   const int pat = s.pivot_at;
   const double pivot = pat < RK_CAP ? (double)s.x[pat] : 0.0;
 
-  // ---- per 16-slot sub-block aggregates straight from registers (a sub-block = one DPP row)
+  // ---- per 8-slot sub-block aggregates straight from registers (a sub-block = half a DPP row)
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     int e = r * RK_THREADS + tid;
@@ -308,8 +339,8 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       vmx = MinMax<T>::row_max(vmx);
       uint64_t si = 0;
       if (kInt) si = row_sum_u64(ok[r] ? (uint64_t)xv[r] : 0ull);
-      if ((lane & 15) == 15) {
-        int b = e >> 4;
+      if ((lane & 7) == 7) {
+        int b = e >> 3;
         s.bs[b + 1] = sd;  // shifted by one: turned into exclusive prefixes below
         s.bq[b + 1] = sq;
         s.bc[b + 1] = sc;
@@ -426,24 +457,16 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   const int sa = a / RK_SB, sb = b / RK_SB;
   if (!slow) {
     const int head_end = sa == sb ? b : (sa + 1) * RK_SB - 1;
-    for (int e = a; e <= head_end; ++e) {
-      if (s.ck[e] & 1u) {
-        T v = s.x[e];
-        if (Ord<T>::finite(v)) {
-          double d = (double)v - pivot;
-          sd += d;
-          sq += d * d;
-          ++dc;
-          if (kInt) isum += (uint64_t)v;
-          mn = MinMax<T>::mn(mn, v);
-          mx = MinMax<T>::mx(mx, v);
-        } else {
-          dc += 0x10000u;
-        }
+    const int tail_begin = sa == sb ? b + 1 : sb * RK_SB;
+    if constexpr (!kInt) {
+      if (!s.nonfinite) {
+      // every staged value is finite and NULL slots hold NaN: no per-slot tests needed
+      for (int e = a; e <= head_end; ++e) slot_add_f64(s.x[e], pivot, sd, sq, dc, mn, mx);
+      for (int e = tail_begin; e <= b; ++e) slot_add_f64(s.x[e], pivot, sd, sq, dc, mn, mx);
       }
     }
-    if (sa != sb) {
-      for (int e = sb * RK_SB; e <= b; ++e) {
+    if (kInt || s.nonfinite) {
+      for (int e = a; e <= b; e = (e == head_end ? tail_begin : e + 1)) {
         if (s.ck[e] & 1u) {
           T v = s.x[e];
           if (Ord<T>::finite(v)) {
@@ -459,16 +482,21 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
           }
         }
       }
-      const int m0 = sa + 1, m1 = sb - 1;
-      if (m0 <= m1) {
-        sd += s.bs[m1 + 1] - s.bs[m0];
-        sq += s.bq[m1 + 1] - s.bq[m0];
-        dc += s.bc[m1 + 1] - s.bc[m0];
-        if (kInt) isum += s.bi[m1 + 1] - s.bi[m0];
-        const int lv = 31 - __clz(m1 - m0 + 1);
-        mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.mn[lv][m0], s.mn[lv][m1 + 1 - (1 << lv)]));
-        mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.mx[lv][m0], s.mx[lv][m1 + 1 - (1 << lv)]));
+    }
+    const int m0 = sa + 1, m1 = sb - 1;
+    if (m0 <= m1) {
+      sd += s.bs[m1 + 1] - s.bs[m0];
+      sq += s.bq[m1 + 1] - s.bq[m0];
+      dc += s.bc[m1 + 1] - s.bc[m0];
+      if (kInt) isum += s.bi[m1 + 1] - s.bi[m0];
+      int lv = 31 - __clz(m1 - m0 + 1);
+      if (lv > RK_LEVELS - 1) {  // more than 255 whole sub-blocks: a third span covers the middle
+        lv = RK_LEVELS - 1;
+        mn = MinMax<T>::mn(mn, s.mn[lv][m0 + (1 << lv)]);
+        mx = MinMax<T>::mx(mx, s.mx[lv][m0 + (1 << lv)]);
       }
+      mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.mn[lv][m0], s.mn[lv][m1 + 1 - (1 << lv)]));
+      mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.mx[lv][m0], s.mx[lv][m1 + 1 - (1 << lv)]));
     }
     slow = (dc >> 16) != 0;  // a non-finite value inside the frame
   }
@@ -482,14 +510,15 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   }
   const int64_t cnt = dc & 0xffffu;
   const double nd = (double)cnt;
-  const double mean = cnt ? pivot + sd / nd : 0.0;
+  const double inv_n = cnt ? fast_rcp(nd) : 0.0;
+  const double mean = cnt ? pivot + sd * inv_n : 0.0;
   T sum;
   if constexpr (kInt) sum = (T)isum;
   else sum = (T)(nd * pivot + sd);
   double stddev = 0.0;
   if (cnt > 1) {
     const bool same = mn == mx;  // all values identical: Spark's m2 is exactly 0
-    double m2 = same ? 0.0 : sq - sd * sd / nd;
+    double m2 = same ? 0.0 : sq - sd * sd * inv_n;
     // The prefix difference carries an absolute error of a few ulps of the running total.
     // When the frame's spread is tiny against that total, redo it as a corrected two-pass
     // sum around the frame mean (rare: near-constant frames inside a varying region).
@@ -505,9 +534,21 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       m2 = acc - lin * lin / nd;
     }
     if (m2 < 0.0) m2 = 0.0;
-    stddev = sqrt(m2 / (nd - 1.0));
+    stddev = fast_sqrt(m2 * fast_rcp(nd - 1.0));
   }
-  rs_store<T>(o, i, cnt, mean, mn, mx, sum, cnt > 1, stddev, (cki & 1u) != 0, (double)s.x[li]);
+  // rs_store's arithmetic, with the reciprocal form of the zscore division
+  {
+    const bool okk = cnt > 0, sd_ok = cnt > 1;
+    o.count[i] = cnt;
+    o.mean[i] = okk ? mean : 0.0;
+    o.mn[i] = okk ? mn : (T)0;
+    o.mx[i] = okk ? mx : (T)0;
+    o.sum[i] = okk ? sum : (T)0;
+    o.stddev[i] = sd_ok ? stddev : 0.0;
+    const bool z_ok = (cki & 1u) && sd_ok && stddev != 0.0;  // Spark Divide: NULL on a zero divisor
+    o.zscore[i] = z_ok ? ((double)s.x[li] - mean) * fast_rcp(stddev) : 0.0;
+    o.valid[i] = (uint8_t)((okk ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
+  }
 }
 
 template <typename T>
