@@ -83,7 +83,7 @@ KERNEL_BYTES_PER_ROW = {
     "radix_hist_kernel": 8.0,         # sort word in
     "range_stats_kernel<T>": 81.0,    # word 8 + metric 8 + row id 4 in; 7 stats x 8 + perm 4 + flags 1 out
     "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out
-    "gather_sorted_kernel<T>": 20.0,  # perm 4 + value 8 in, value 8 out
+    "radix_scatter_kernel+payload": 40.0,  # pair 12 + metric 8, in and out
     "asof_merge_kernel": 44.0,        # per left row: word 8 + perm 4 in, right word 8 + perm 4 + 2x lastnn 4 in, 3 idx out
     "lastnn_scan_kernel": 16.0,       # word 8 in, 2 x 4 B out
     "lastnn_reduce_kernel": 8.0,

@@ -130,11 +130,15 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 // sorted: 0 = full sort, 1 = rows already in (key, primary, seq) order (no passes), 2 = rows in
 // (primary, seq) order with interleaved keys (a time-ordered feed): the stable passes over the
 // key bits alone finish the job.
+// pay_src / pay_out (optional): an 8-byte column to deliver in sorted order along with the
+// last radix pass, pay_out[p] = pay_src[perm[p]]; *carried reports whether that happened.
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
-                OrderResult *res, hipStream_t st);
+                OrderResult *res, hipStream_t st, const uint64_t *pay_src = nullptr,
+                uint64_t *pay_out = nullptr, bool *carried = nullptr);
 inline int sorted_mode(const RangeInfo &r) { return !r.unsorted ? 1 : (!r.time_unsorted ? 2 : 0); }
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st);
+                       hipStream_t st, const uint64_t *pay_src = nullptr, uint64_t *pay_out = nullptr,
+                       bool *carried = nullptr);
 // One-call form for ops that order a single table.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);

@@ -75,14 +75,6 @@ static void ema_plan(const tmp_ema_args *a, Workspace &ws, EmaPlan *p) {
   p->w = ws.take<double>(TMP_MAX_TAPS);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void take_sorted_kernel(const T *x, const uint32_t *perm, int64_t n,
-                                                             T *out) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = x[perm[i]];
-}
-
 }  // namespace tmp
 
 using namespace tmp;
@@ -122,14 +114,9 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   RangeInfo r;
   TMP_TRY(order_read_ranges(p.ob, &r, st));
   TMP_TRY(order_make_layout(s, r, 1, &lay));
-  bool sorted = r.unsorted == 0;
-  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st));
-  const double *xs = a->x;
-  if (!sorted) {
-    TMP_LAUNCH(take_sorted_kernel<double>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock), st, a->x,
-               res.perm, a->n, p.xs);
-    xs = p.xs;
-  }
+  bool carried = false;
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, (const uint64_t *)a->x, (uint64_t *)p.xs, &carried));
+  const double *xs = carried ? p.xs : a->x;
   int taps = a->n_taps;  // zero taps: the column stays lit(0)
   if (taps > 0)
     TMP_CHECK_HIP(hipMemcpyAsync(p.w, a->weights, sizeof(double) * taps, hipMemcpyHostToDevice, st));

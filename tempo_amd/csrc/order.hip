@@ -237,14 +237,19 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
   }
 }
 
-template <int RS_THREADS, int RS_ITEMS>
+// PAY: the pass also moves one 8-byte payload column, read through the row id
+// (pay_src[row id]) and written next to the pair -- used on the last pass so that the ordered
+// copy of a metric column costs no separate random gather.
+template <int RS_THREADS, int RS_ITEMS, bool PAY>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
-    int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets) {
+    int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
+    const uint64_t *pay_src, uint64_t *pay_out) {
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   __shared__ uint64_t skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
+  __shared__ uint64_t spay[PAY ? RS_TILE : 1];
   __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
   __shared__ uint32_t dstart[RS_RADIX];
   __shared__ uint32_t goff[RS_RADIX];
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __syncthreads();
     uint64_t k[RS_ITEMS];
     uint32_t v[RS_ITEMS];
+    uint64_t pay[PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
 #pragma unroll
@@ -269,6 +275,13 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       bool valid = pos < tile_n;
       k[it] = valid ? kin[tile_base + pos] : 0ull;
       v[it] = valid ? vin[tile_base + pos] : 0u;
+    }
+    if (PAY) {
+#pragma unroll
+      for (int it = 0; it < RS_ITEMS; ++it) {
+        int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+        pay[PAY ? it : 0] = pos < tile_n ? pay_src[v[it]] : 0ull;
+      }
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint32_t p = dstart[d] + whist[wave][d] + rank[it];
         skey[p] = k[it];
         sval[p] = v[it];
+        if (PAY) spay[PAY ? p : 0] = pay[PAY ? it : 0];
       }
     }
     __syncthreads();
@@ -331,6 +345,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint32_t g = goff[d] + ((uint32_t)p - dstart[d]);
         kout[g] = kk;
         vout[g] = sval[p];
+        if (PAY) pay_out[g] = spay[PAY ? p : 0];
       }
     }
     __syncthreads();
@@ -396,26 +411,41 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
   return TMP_OK;
 }
 
-// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].
-template <int THREADS, int ITEMS>
-static int radix_passes_cfg(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                            hipStream_t st) {
+// One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.
+template <int THREADS, int ITEMS, bool PAY>
+static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
+                           const uint64_t *pay_src, uint64_t *pay_out) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
+  uint32_t mask = (1u << nbits) - 1;
+  {
+    ProfScope ps("radix_hist_kernel", st);
+    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
+                       b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts);
+  }
+  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
+  {
+    ProfScope ps(PAY ? "radix_scatter_kernel+payload" : "radix_scatter_kernel", st);
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, PAY>), dim3(g.grid), dim3(THREADS), 0, st,
+                       b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                       g.tiles_per_block, b.counts, pay_src, pay_out);
+  }
+}
+
+// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].  With
+// pay_src / pay_out the last pass also delivers pay_out[p] = pay_src[perm[p]]; *carried tells
+// whether a pass ran at all (no pass: the order is the identity and pay_out is untouched).
+int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                       hipStream_t st, const uint64_t *pay_src, uint64_t *pay_out, bool *carried) {
   int cur = 0;
+  if (carried) *carried = false;
   for (int lo = lo_bit; lo < hi_bit; lo += 8) {
     int nbits = hi_bit - lo < 8 ? hi_bit - lo : 8;
-    uint32_t mask = (1u << nbits) - 1;
-    {
-      ProfScope ps("radix_hist_kernel", st);
-      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts);
-    }
-    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
-    {
-      ProfScope ps("radix_scatter_kernel", st);
-      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                         g.tiles_per_block, b.counts);
+    bool last = lo + 8 >= hi_bit;
+    if (last && pay_src && pay_out) {
+      radix_one_pass<1024, 4, true>(b, n, cur, lo, nbits, st, pay_src, pay_out);
+      if (carried) *carried = true;
+    } else {
+      radix_one_pass<1024, 8, false>(b, n, cur, lo, nbits, st, nullptr, nullptr);
     }
     cur ^= 1;
   }
@@ -425,22 +455,10 @@ static int radix_passes_cfg(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, 
   return TMP_OK;
 }
 
-int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st) {
-  static int cfg = getenv("TMP_SORT_CFG") ? atoi(getenv("TMP_SORT_CFG")) : 0;
-  switch (cfg) {
-    case 1: return radix_passes_cfg<512, 8>(b, n, lo_bit, hi_bit, res, st);
-    case 2: return radix_passes_cfg<1024, 4>(b, n, lo_bit, hi_bit, res, st);
-    case 3: return radix_passes_cfg<512, 16>(b, n, lo_bit, hi_bit, res, st);
-    case 4: return radix_passes_cfg<256, 8>(b, n, lo_bit, hi_bit, res, st);
-    case 5: return radix_passes_cfg<1024, 8>(b, n, lo_bit, hi_bit, res, st);
-    case 6: return radix_passes_cfg<256, 16>(b, n, lo_bit, hi_bit, res, st);
-    default: return radix_passes_cfg<1024, 8>(b, n, lo_bit, hi_bit, res, st);
-  }
-}
-
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
-                OrderResult *res, hipStream_t st) {
+                OrderResult *res, hipStream_t st, const uint64_t *pay_src, uint64_t *pay_out,
+                bool *carried) {
+  if (carried) *carried = false;
   res->comp = b.comp[0];
   res->perm = b.idx[0];
   if (s.n <= 0) return TMP_OK;
@@ -451,7 +469,8 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
                      s.seq_valid, lay, s.n_masks, mp, b.comp[0], b.idx[0]);
   TMP_CHECK_HIP(hipGetLastError());
   if (sorted == 1) return TMP_OK;
-  return order_radix_passes(b, s.n, sorted == 2 ? lay.key_shift() : lay.low_bits, lay.total_bits(), res, st);
+  return order_radix_passes(b, s.n, sorted == 2 ? lay.key_shift() : lay.low_bits, lay.total_bits(), res, st,
+                            pay_src, pay_out, carried);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,

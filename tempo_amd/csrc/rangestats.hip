@@ -551,14 +551,6 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBlock) void gather_sorted_kernel(const T *x, const uint32_t *perm,
-                                                               int64_t n, T *out) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = x[perm[i]];
-}
-
 struct RsPlan {
   OrderBuffers ob;
   uint64_t *xs;
@@ -583,13 +575,11 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   Layout lay;
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   OrderResult res;
-  bool sorted = r.unsorted == 0;
-  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st));
-  const T *xs = (const T *)a->x;
-  if (!sorted) {
-    TMP_LAUNCH(gather_sorted_kernel<T>, dim3(grid_for(a->n, kBlock * 4, 16384)), dim3(kBlock), st, (const T *)a->x, res.perm, a->n, (T *)p.xs);
-    xs = (const T *)p.xs;
-  }
+  // the metric column rides along with the last radix pass; if no pass runs the rows are
+  // already in order and the column is used where it is
+  bool carried = false;
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, (const uint64_t *)a->x, p.xs, &carried));
+  const T *xs = carried ? (const T *)p.xs : (const T *)a->x;
   RsOut<T> o;
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
