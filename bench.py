@@ -114,8 +114,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # TEMPO_BENCH_FORCE_SHUFFLE=1 runs the shuffle path on one GPU too (a one-rank RCCL group):
+    # a way to rehearse the --gpus N code path where only one GPU is at hand
+    force_shuffle = os.environ.get("TEMPO_BENCH_FORCE_SHUFFLE") == "1"
+    if world > 1 or force_shuffle:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         from tempo_amd.dist import shuffle_by_key
 
@@ -133,7 +140,7 @@ def main():
     def step():
         q = tq
         t = tk
-        if world > 1:
+        if dist is not None:
             # Exchange hashpartitioning(key): bucket on device, one all-to-all per column
             _lib.profile_tag(0)
             kl, (tl, pr), _, _ = shuffle_by_key(tq["key_l"], [tq["ts_l"], tq["trade_pr"]])

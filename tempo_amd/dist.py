@@ -3,13 +3,17 @@
 Spark's Exchange hashpartitioning(partitionCols) in front of every Window / groupBy
 (python/tempo/tsdf.py:121, :571; python/tempo/resample.py:63) becomes one all-to-all per
 column: rows are bucketed on the device by owner = mix(key) % world_size
-(tmp_hash_partition), exchanged with all_to_all_single, and every later operator runs locally
-on the series a rank owns -- no other collective is on the data path.
+(tmp_hash_partition), exchanged with all_to_all, and every later operator runs locally on the
+series a rank owns -- no other collective is on the data path.
 """
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+# Largest single message handed to the collective, in bytes.  Columns of 10^9 rows are several
+# GB per peer; they go out as a sequence of all-to-alls over row ranges of at most this size.
+MAX_MESSAGE_BYTES = 1 << 30
 
 
 def _hip_partition(key, n_parts):
@@ -18,6 +22,27 @@ def _hip_partition(key, n_parts):
 
 def _hip_take(col, perm):
     return ops.gather(col, perm, want_valid=False)[0]
+
+
+def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
+    """All-to-all of one column in `rounds` slices: round c moves rows [c*R, (c+1)*R) of what
+    every rank sends to every other rank.  Views only, nothing is copied."""
+    s_off = [0]
+    for v in send_l[:-1]:
+        s_off.append(s_off[-1] + v)
+    r_off = [0]
+    for v in recv_l[:-1]:
+        r_off.append(r_off[-1] + v)
+    if rounds == 1:
+        dist.all_to_all_single(got, staged, output_split_sizes=recv_l, input_split_sizes=send_l, group=group)
+        return
+    for c in range(rounds):
+        lo = c * rows_per_round
+        ins = [staged[s_off[r] + min(lo, send_l[r]): s_off[r] + min(lo + rows_per_round, send_l[r])]
+               for r in range(len(send_l))]
+        outs = [got[r_off[r] + min(lo, recv_l[r]): r_off[r] + min(lo + rows_per_round, recv_l[r])]
+                for r in range(len(recv_l))]
+        dist.all_to_all(outs, ins, group=group)
 
 
 def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None):
@@ -35,14 +60,19 @@ def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None):
     send = counts.to(torch.int64)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
+    # every rank must run the same number of rounds: size them by the largest pairwise message
+    biggest = torch.maximum(send.max(), recv.max()).reshape(1)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
     send_l = [int(v) for v in send.cpu().tolist()]
     recv_l = [int(v) for v in recv.cpu().tolist()]
+    biggest = int(biggest.item())
     n_recv = sum(recv_l)
     out_cols = []
     for col in [key] + list(columns):
         staged = take_fn(col, perm)
         got = torch.empty(n_recv, dtype=col.dtype, device=col.device)
-        dist.all_to_all_single(got, staged, output_split_sizes=recv_l, input_split_sizes=send_l,
-                               group=group)
+        rows_per_round = max(1, MAX_MESSAGE_BYTES // col.element_size())
+        rounds = max(1, -(-biggest // rows_per_round))
+        _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group)
         out_cols.append(got)
     return out_cols[0], out_cols[1:], send_l, recv_l
