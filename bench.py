@@ -4,8 +4,8 @@
 One step = one pass of the hot path over one batch of device-resident synthetic input:
   1. asofJoin of `rows/2` trades against `rows/2` quotes (10 000 Zipf(1.2) symbols, uniform
      microsecond timestamps over one trading day, skew mode tsPartitionVal=10 fraction=0.1,
-     three joined right columns, two of them with 1 % NULLs), including the gathers that
-     materialise the joined table (left payload + three right columns) in (key, ts) order;
+     three joined right columns, two of them with 1 % NULLs), producing the joined table
+     (key, ts, left payload + three right columns with validity) in (key, ts) order;
   2. withRangeStats(rangeBackWindowSecs=600) of one fp64 metric over `rows` ticks
      (100 symbols, Exp(1 s) inter-arrival per symbol, 0.5 % NULLs).
 value = rows consumed by both operators (2 x rows) / step time, inputs already in HBM.
@@ -83,8 +83,12 @@ KERNEL_BYTES_PER_ROW = {
     "radix_hist_kernel": 8.0,         # sort word in
     "range_stats_kernel<T>": 81.0,    # word 8 + metric 8 + row id 4 in; 7 stats x 8 + perm 4 + flags 1 out
     "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out
-    "radix_scatter_kernel+payload": 40.0,  # pair 12 + metric 8, in and out
-    "asof_merge_kernel": 44.0,        # per left row: word 8 + perm 4 in, right word 8 + perm 4 + 2x lastnn 4 in, 3 idx out
+    "radix_scatter_kernel+payload": 40.0,  # pair 12 + one 8 B payload column, in and out
+    "pack_rows_kernel": 56.0,         # 3 x 8 B columns in, one 32 B record out
+    # per left row: word 8 + row id 4 + left payload 8 in; right word 8 + 2 x last-non-null 4 +
+    # row id 4 + one 32 B payload record in (the two sides have equal row counts);
+    # row id 4 + key 4 + ts 8 + left payload 8 + 3 x (value 8 + flag 1) out
+    "asof_merge_kernel": 123.0,
     "lastnn_scan_kernel": 16.0,       # word 8 in, 2 x 4 B out
     "lastnn_reduce_kernel": 8.0,
     "range_scan_kernel": 12.0,        # key 4 + ts 8 in
@@ -150,18 +154,14 @@ def main():
             kk, (tt, xx, xv), _, _ = shuffle_by_key(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
             t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
         _lib.profile_tag(1)
-        # joined table in (key, ts) order, as Spark's window leaves it: key / ts come back
-        # ordered, the left payload is gathered through perm, the right columns through the
-        # match indices
-        row, midx, missing, perm, key_s, ts_s = ops.asof_join(
-            q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, masks=[q["bid_valid"], q["ask_valid"]],
-            ts_partition_val=10, fraction=0.1, sorted_output=True)
-        l_pr, _ = ops.gather(q["trade_pr"], perm, want_valid=False)
-        r_ts, _ = ops.gather(q["ts_r"], row)
-        r_bid, _ = ops.gather(q["bid"], midx[0])
-        r_ask, _ = ops.gather(q["ask"], midx[1])
+        # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
+        # the left side and the three joined right columns, written by the merge itself
+        j = ops.asof_join_table(
+            q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
+            [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
+            skip_nulls=True, ts_partition_val=10, fraction=0.1)
         n1 = q["ts_l"].numel() + q["ts_r"].numel()
-        del row, midx, perm, key_s, ts_s, l_pr, r_ts, r_bid, r_ask
+        del j
         _lib.profile_tag(2)
         out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
         n2 = t["ts"].numel()

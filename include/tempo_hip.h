@@ -96,6 +96,7 @@ int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t workspace_byt
  * have to be gathered through out_perm.
  */
 #define TMP_MAX_MASKS 16
+#define TMP_MAX_JOIN_COLS 16
 
 typedef struct {
   int64_t n_left;
@@ -119,6 +120,24 @@ typedef struct {
   int32_t *out_perm;     /* [n_left], required when sorted_output != 0 */
   int32_t *out_key;      /* [n_left] or NULL (sorted_output only) */
   int64_t *out_ts;       /* [n_left] or NULL (sorted_output only) */
+  /* Fused payload join (sorted_output only, 8-byte element columns, HOST arrays of device
+   * pointers, at most TMP_MAX_JOIN_COLS per side).  The columns ride along with the last
+   * radix pass of their table, so the joined table is written with streaming accesses only:
+   *   out_left_cols[c][p]  = left_cols[c][out_perm[p]]
+   *   out_right_cols[c][p] = right_cols[c][j], j = the right row chosen by right_col_rule[c]
+   *                          (-1: last visible row; m: last visible row with mask m valid)
+   *   out_right_valid[c][p] = a row was chosen and (right_col_valid[c] == -1 or mask
+   *                          right_col_valid[c] is 1 on that row)
+   * With these, out_idx may be NULL. */
+  int32_t n_left_cols;
+  const void *const *left_cols;
+  void *const *out_left_cols;
+  int32_t n_right_cols;
+  const void *const *right_cols;
+  const int32_t *right_col_rule;  /* host */
+  const int32_t *right_col_valid; /* host */
+  void *const *out_right_cols;
+  uint8_t *const *out_right_valid; /* entries may be NULL */
   int32_t *out_missing;  /* [1 + n_masks] */
 } tmp_asof_args;
 

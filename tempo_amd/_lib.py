@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtempo_hip.so")
 
 TMP_MAX_MASKS = 16
+TMP_MAX_JOIN_COLS = 16
 TMP_MAX_TAPS = 1024
 TMP_MAX_FEATURES = 64
 TMP_MAX_COLS = 64
@@ -30,7 +31,12 @@ class AsofArgs(C.Structure):
                 ("n_masks", C.c_int32), ("masks", C.POINTER(_vp)), ("skew", C.c_int32),
                 ("v_is_int", C.c_int32), ("ts_partition_val", C.c_double),
                 ("one_minus_fraction", C.c_double), ("out_idx", _vp), ("sorted_output", C.c_int32),
-                ("out_perm", _vp), ("out_key", _vp), ("out_ts", _vp), ("out_missing", _vp)]
+                ("out_perm", _vp), ("out_key", _vp), ("out_ts", _vp),
+                ("n_left_cols", C.c_int32), ("left_cols", C.POINTER(_vp)), ("out_left_cols", C.POINTER(_vp)),
+                ("n_right_cols", C.c_int32), ("right_cols", C.POINTER(_vp)),
+                ("right_col_rule", C.POINTER(C.c_int32)), ("right_col_valid", C.POINTER(C.c_int32)),
+                ("out_right_cols", C.POINTER(_vp)), ("out_right_valid", C.POINTER(_vp)),
+                ("out_missing", _vp)]
 
 
 class RangeStatsArgs(C.Structure):

@@ -20,7 +20,16 @@ struct AsofPlan {
   OrderBuffers lb, rb;
   int32_t *lastnn;   // [n_masks][n_right]
   int32_t *unit_agg; // [n_masks][kUnits]
+  uint64_t *lrec;    // [n_left][stride] packed left payload records (2+ columns)
+  uint64_t *rrec;    // [n_right][stride] packed right payload records (2+ columns)
 };
+
+// 8-byte words per packed payload record: a power of two up to 4 (so that a record never
+// straddles a 32-byte sector), then multiples of 4.
+static inline int rec_stride(int n_cols) {
+  if (n_cols <= 2) return n_cols < 1 ? 1 : n_cols;
+  return (n_cols + 3) & ~3;
+}
 
 constexpr int kUnits = 4096;     // waves that each scan one contiguous slice of the right side
 constexpr int kUnitBlock = 256;  // 4 waves per block
@@ -195,9 +204,38 @@ __device__ __forceinline__ int64_t upper_bound(const uint64_t *comp, int64_t lo,
   return lo;
 }
 
-// id of right position j, reusing the id already fetched for the row rule when it is valid
-__device__ __forceinline__ int32_t row_src_or(const uint32_t *perm_r, int32_t j, int32_t row_src) {
-  return row_src >= 0 ? row_src : (int32_t)perm_r[j];
+// Payload columns of the fused join.  A table with two or more payload columns is first packed
+// into row records (pack_rows_kernel) so that the one random access a joined row costs
+// brings all its columns; a single column is read where it lies (stride 1).
+struct JoinCols {
+  int n_left, lstride;
+  const uint64_t *lrec;
+  uint64_t *lout[TMP_MAX_JOIN_COLS];
+  int n, rstride;
+  const uint64_t *rrec;
+  uint64_t *out[TMP_MAX_JOIN_COLS];
+  uint8_t *out_valid[TMP_MAX_JOIN_COLS];
+  int8_t rule[TMP_MAX_JOIN_COLS];   // -1: last visible row; m: last visible row with mask m valid
+  int8_t vmask[TMP_MAX_JOIN_COLS];  // -1: never NULL once matched; m: NULL where mask m is 0
+};
+
+struct PackCols {
+  int n, stride;
+  const uint64_t *src[TMP_MAX_JOIN_COLS];
+};
+
+// rec[i][c] = src[c][i]; every column is read once, front to back.
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(PackCols pc, int64_t n, uint64_t *rec) {
+  int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    uint64_t *r = rec + (size_t)i * pc.stride;
+    for (int c = 0; c < pc.stride; c += 2) {  // stride is even here (2 or a multiple of 4)
+      ulonglong2 v;
+      v.x = c < pc.n ? pc.src[c][i] : 0ull;
+      v.y = c + 1 < pc.n ? pc.src[c + 1][i] : 0ull;
+      *reinterpret_cast<ulonglong2 *>(r + c) = v;
+    }
+  }
 }
 
 constexpr int kMergeRows = 4;     // left rows per thread
@@ -210,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
     SkewParams sp, int32_t *out_idx, int32_t *out_missing, int sorted_output, int32_t *out_perm,
-    int32_t *out_key, int64_t *out_ts) {
+    int32_t *out_key, int64_t *out_ts, JoinCols jc) {
   __shared__ int64_t bounds[2];
   __shared__ uint64_t rw[kMergeRight];
   const int low = lay.low_bits;
@@ -266,25 +304,72 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       if (out_key) out_key[i] = (int32_t)key_l;
       if (out_ts) out_ts[i] = lay.prim_of(wl);
     }
+    // jrow: position (ordered right side) of the last visible row, or -1
+    const int64_t jrow = (same && (!sp.enabled || bracket_visible(lay.prim_of(wr_row), part_l, sp))) ? jr : -1;
     int32_t row_src = -1;
-    if (same && (!sp.enabled || bracket_visible(lay.prim_of(wr_row), part_l, sp)))
-      row_src = (int32_t)perm_r[jr];
-    int32_t *rec = out_idx + (size_t)dst * (1 + n_masks);
-    rec[0] = row_src;
-    miss_row |= row_src < 0;
+    int32_t *rec = out_idx ? out_idx + (size_t)dst * (1 + n_masks) : nullptr;
+    if (rec) {
+      if (jrow >= 0) row_src = (int32_t)perm_r[jrow];
+      rec[0] = row_src;
+    }
+    miss_row |= jrow < 0;
+    if (jc.n_left) {  // left payload of this row (sorted_output only)
+      const uint64_t *lr = jc.lrec + (size_t)src_row * jc.lstride;
+      for (int c = 0; c < jc.n_left; ++c) jc.lout[c][i] = lr[c];
+    }
+    // the matched row's payload record: up to four columns are held in registers
+    const uint64_t *rr = nullptr;
+    uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (jc.n) {
+      if (jrow >= 0) {
+        if (row_src < 0) row_src = (int32_t)perm_r[jrow];
+        rr = jc.rrec + (size_t)(uint32_t)row_src * jc.rstride;
+        if (jc.rstride == 1) q0 = rr[0];
+        else {
+          ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rr);
+          q0 = a.x; q1 = a.y;
+          if (jc.rstride >= 4) {
+            ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(rr + 2);
+            q2 = b.x; q3 = b.y;
+          }
+        }
+      }
+      for (int c = 0; c < jc.n; ++c) {  // columns that follow the row rule
+        if (jc.rule[c] >= 0) continue;
+        bool okv = jrow >= 0 && (jc.vmask[c] < 0 || ((wr_row >> jc.vmask[c]) & 1ull));
+        uint64_t v = c == 0 ? q0 : c == 1 ? q1 : c == 2 ? q2 : c == 3 ? q3 : (rr ? rr[c] : 0ull);
+        jc.out[c][dst] = okv ? v : 0ull;
+        if (jc.out_valid[c]) jc.out_valid[c][dst] = okv ? 1 : 0;
+      }
+    }
     for (int m = 0; m < n_masks; ++m) {
-      int32_t src = -1;
+      int64_t jm = -1;  // position of the last visible row whose mask m is valid, or -1
+      uint64_t wm = 0;
       if (same) {
         int32_t j = lastnn[(size_t)m * n_right + jr];
         if (j >= 0) {
-          uint64_t wr = (staged && j >= blo) ? rw[j - blo] : comp_r[j];
-          if (lay.key_of(wr) == key_l &&
-              (!sp.enabled || bracket_visible(lay.prim_of(wr), part_l, sp)))
-            src = j == jr ? row_src_or(perm_r, j, row_src) : (int32_t)perm_r[j];
+          wm = (staged && j >= blo) ? rw[j - blo] : comp_r[j];
+          if (lay.key_of(wm) == key_l && (!sp.enabled || bracket_visible(lay.prim_of(wm), part_l, sp))) jm = j;
         }
       }
-      rec[1 + m] = src;
-      miss_mask |= (uint32_t)(src < 0) << m;
+      if (rec) rec[1 + m] = jm < 0 ? -1 : (jm == jrow && row_src >= 0 ? row_src : (int32_t)perm_r[jm]);
+      miss_mask |= (uint32_t)(jm < 0) << m;
+      const uint64_t *rm = nullptr;
+      for (int c = 0; c < jc.n; ++c) {
+        if (jc.rule[c] != m) continue;
+        bool okv = jm >= 0 && (jc.vmask[c] < 0 || ((wm >> jc.vmask[c]) & 1ull));
+        uint64_t v = 0;
+        if (okv) {
+          if (jm == jrow) {
+            v = c == 0 ? q0 : c == 1 ? q1 : c == 2 ? q2 : c == 3 ? q3 : rr[c];
+          } else {
+            if (!rm) rm = jc.rrec + (size_t)perm_r[jm] * jc.rstride;
+            v = rm[c];
+          }
+        }
+        jc.out[c][dst] = v;
+        if (jc.out_valid[c]) jc.out_valid[c][dst] = okv ? 1 : 0;
+      }
     }
   }
   if (__any(miss_row) && (threadIdx.x & 63) == 0) atomicOr(&out_missing[0], 1);
@@ -305,6 +390,9 @@ static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(nm * kUnits);
+  const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
+  p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
+  p->rrec = ws.take<uint64_t>(nrc >= 2 ? (size_t)rec_stride(nrc) * (size_t)a->n_right : 2);
 }
 
 }  // namespace tmp
@@ -323,7 +411,22 @@ static int asof_validate(const tmp_asof_args *a) {
   TMP_REQUIRE(a->n_left == 0 || a->ts_left, TMP_EINVAL, "tmp_asof_join: ts_left is null");
   TMP_REQUIRE(a->n_right == 0 || a->ts_right, TMP_EINVAL, "tmp_asof_join: ts_right is null");
   TMP_REQUIRE(a->n_masks == 0 || a->masks, TMP_EINVAL, "tmp_asof_join: masks missing");
-  TMP_REQUIRE(a->n_left == 0 || a->out_idx, TMP_EINVAL, "tmp_asof_join: out_idx is null");
+  const bool fused = a->sorted_output && (a->n_left_cols > 0 || a->n_right_cols > 0);
+  TMP_REQUIRE(a->n_left == 0 || a->out_idx || fused, TMP_EINVAL, "tmp_asof_join: out_idx is null");
+  TMP_REQUIRE(a->sorted_output || (a->n_left_cols == 0 && a->n_right_cols == 0), TMP_EINVAL,
+              "tmp_asof_join: payload columns need sorted_output");
+  TMP_REQUIRE(a->n_left_cols >= 0 && a->n_left_cols <= TMP_MAX_JOIN_COLS && a->n_right_cols >= 0 &&
+                  a->n_right_cols <= TMP_MAX_JOIN_COLS,
+              TMP_EINVAL, "tmp_asof_join: at most %d payload columns per side", TMP_MAX_JOIN_COLS);
+  TMP_REQUIRE(a->n_left_cols == 0 || (a->left_cols && a->out_left_cols), TMP_EINVAL,
+              "tmp_asof_join: left payload arrays missing");
+  TMP_REQUIRE(a->n_right_cols == 0 ||
+                  (a->right_cols && a->out_right_cols && a->right_col_rule && a->right_col_valid && a->out_right_valid),
+              TMP_EINVAL, "tmp_asof_join: right payload arrays missing");
+  for (int c = 0; c < a->n_right_cols; ++c)
+    TMP_REQUIRE(a->right_col_rule[c] >= -1 && a->right_col_rule[c] < a->n_masks && a->right_col_valid[c] >= -1 &&
+                    a->right_col_valid[c] < a->n_masks,
+                TMP_EINVAL, "tmp_asof_join: right column %d refers to a mask that was not given", c);
   TMP_REQUIRE(a->n_left == 0 || !a->sorted_output || a->out_perm, TMP_EINVAL,
               "tmp_asof_join: out_perm is required with sorted_output");
   TMP_REQUIRE(a->out_missing, TMP_EINVAL, "tmp_asof_join: out_missing is null");
@@ -388,6 +491,48 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
   TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
 
+  // payload columns of the fused join: packed into row records when a side has several
+  const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
+  JoinCols jc;
+  memset(&jc, 0, sizeof(jc));
+  jc.n_left = nlc;
+  jc.n = a->n_right > 0 ? nrc : 0;
+  jc.lstride = rec_stride(nlc);
+  jc.rstride = rec_stride(nrc);
+  PackCols pl, pr;
+  memset(&pl, 0, sizeof(pl));
+  memset(&pr, 0, sizeof(pr));
+  for (int c = 0; c < nlc; ++c) {
+    TMP_REQUIRE(a->left_cols[c] && a->out_left_cols[c], TMP_EINVAL, "tmp_asof_join: left payload column %d is null", c);
+    pl.src[c] = (const uint64_t *)a->left_cols[c];
+    jc.lout[c] = (uint64_t *)a->out_left_cols[c];
+  }
+  for (int c = 0; c < nrc; ++c) {
+    TMP_REQUIRE(a->n_right == 0 || a->right_cols[c], TMP_EINVAL, "tmp_asof_join: right payload column %d is null", c);
+    TMP_REQUIRE(a->out_right_cols[c], TMP_EINVAL, "tmp_asof_join: right output column %d is null", c);
+    pr.src[c] = (const uint64_t *)a->right_cols[c];
+    jc.out[c] = (uint64_t *)a->out_right_cols[c];
+    jc.out_valid[c] = a->out_right_valid[c];
+    jc.rule[c] = (int8_t)a->right_col_rule[c];
+    jc.vmask[c] = (int8_t)a->right_col_valid[c];
+  }
+  if (nrc > 0 && a->n_right == 0) {  // nothing to match: every joined column is NULL
+    for (int c = 0; c < nrc; ++c) {
+      TMP_CHECK_HIP(hipMemsetAsync(a->out_right_cols[c], 0, sizeof(uint64_t) * a->n_left, st));
+      if (a->out_right_valid[c]) TMP_CHECK_HIP(hipMemsetAsync(a->out_right_valid[c], 0, a->n_left, st));
+    }
+  }
+  jc.lrec = nlc == 1 ? pl.src[0] : p.lrec;
+  jc.rrec = nrc == 1 ? pr.src[0] : p.rrec;
+  if (nlc >= 2) {
+    pl.n = nlc; pl.stride = jc.lstride;
+    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_left, kBlock, 8192)), dim3(kBlock), st, pl, a->n_left, p.lrec);
+  }
+  if (nrc >= 2 && a->n_right > 0) {
+    pr.n = nrc; pr.stride = jc.rstride;
+    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right, kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
+  }
+
   if (a->n_masks > 0) {
     ScanGeom g = scan_geom(a->n_right);
     int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
@@ -406,7 +551,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
                      ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts);
+                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

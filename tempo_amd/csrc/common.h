@@ -130,15 +130,24 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 // sorted: 0 = full sort, 1 = rows already in (key, primary, seq) order (no passes), 2 = rows in
 // (primary, seq) order with interleaved keys (a time-ordered feed): the stable passes over the
 // key bits alone finish the job.
-// pay_src / pay_out (optional): an 8-byte column to deliver in sorted order along with the
-// last radix pass, pay_out[p] = pay_src[perm[p]]; *carried reports whether that happened.
+// Payload columns that ride along with the last radix pass (8-byte elements).
+constexpr int kMaxPay = 1;
+struct PayPtrs {
+  int n;
+  const uint64_t *src[kMaxPay];
+  uint64_t *out[kMaxPay];
+};
+// pay_src / pay_out (optional, n_pay columns of 8-byte elements): delivered in sorted order
+// along with the last radix pass, pay_out[c][p] = pay_src[c][perm[p]]; *carried reports
+// whether that happened (it does not when the rows need no pass).
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
-                OrderResult *res, hipStream_t st, const uint64_t *pay_src = nullptr,
-                uint64_t *pay_out = nullptr, bool *carried = nullptr);
+                OrderResult *res, hipStream_t st, int n_pay = 0,
+                const uint64_t *const *pay_src = nullptr, uint64_t *const *pay_out = nullptr,
+                bool *carried = nullptr);
 inline int sorted_mode(const RangeInfo &r) { return !r.unsorted ? 1 : (!r.time_unsorted ? 2 : 0); }
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st, const uint64_t *pay_src = nullptr, uint64_t *pay_out = nullptr,
-                       bool *carried = nullptr);
+                       hipStream_t st, int n_pay = 0, const uint64_t *const *pay_src = nullptr,
+                       uint64_t *const *pay_out = nullptr, bool *carried = nullptr);
 // One-call form for ops that order a single table.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);

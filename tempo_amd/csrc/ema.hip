@@ -115,7 +115,9 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   TMP_TRY(order_read_ranges(p.ob, &r, st));
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   bool carried = false;
-  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, (const uint64_t *)a->x, (uint64_t *)p.xs, &carried));
+  const uint64_t *pay_src[1] = {(const uint64_t *)a->x};
+  uint64_t *pay_out[1] = {(uint64_t *)p.xs};
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
   const double *xs = carried ? p.xs : a->x;
   int taps = a->n_taps;  // zero taps: the column stays lit(0)
   if (taps > 0)

@@ -237,19 +237,20 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
   }
 }
 
-// PAY: the pass also moves one 8-byte payload column, read through the row id
-// (pay_src[row id]) and written next to the pair -- used on the last pass so that the ordered
-// copy of a metric column costs no separate random gather.
-template <int RS_THREADS, int RS_ITEMS, bool PAY>
+// NPAY > 0: the pass also moves up to NPAY 8-byte payload columns, read through the row id
+// (src[row id]) and written next to the pair -- used on the last pass so that ordered copies
+// of payload columns cost no separate random gather (the scatter writes them in digit runs).
+template <int RS_THREADS, int RS_ITEMS, int NPAY>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
-    const uint64_t *pay_src, uint64_t *pay_out) {
+    PayPtrs pp) {
+  constexpr bool PAY = NPAY > 0;
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   __shared__ uint64_t skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
-  __shared__ uint64_t spay[PAY ? RS_TILE : 1];
+  __shared__ uint64_t spay[PAY ? NPAY : 1][PAY ? RS_TILE : 1];
   __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
   __shared__ uint32_t dstart[RS_RADIX];
   __shared__ uint32_t goff[RS_RADIX];
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __syncthreads();
     uint64_t k[RS_ITEMS];
     uint32_t v[RS_ITEMS];
-    uint64_t pay[PAY ? RS_ITEMS : 1];
+    uint64_t pay[PAY ? NPAY : 1][PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
 #pragma unroll
@@ -280,7 +281,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
         int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-        pay[PAY ? it : 0] = pos < tile_n ? pay_src[v[it]] : 0ull;
+#pragma unroll
+        for (int c = 0; c < NPAY; ++c)
+          pay[c][PAY ? it : 0] = (pos < tile_n && c < pp.n) ? pp.src[c][v[it]] : 0ull;
       }
     }
 #pragma unroll
@@ -332,7 +335,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint32_t p = dstart[d] + whist[wave][d] + rank[it];
         skey[p] = k[it];
         sval[p] = v[it];
-        if (PAY) spay[PAY ? p : 0] = pay[PAY ? it : 0];
+        if (PAY) {
+#pragma unroll
+          for (int c = 0; c < NPAY; ++c) spay[c][PAY ? p : 0] = pay[c][PAY ? it : 0];
+        }
       }
     }
     __syncthreads();
@@ -345,7 +351,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint32_t g = goff[d] + ((uint32_t)p - dstart[d]);
         kout[g] = kk;
         vout[g] = sval[p];
-        if (PAY) pay_out[g] = spay[PAY ? p : 0];
+        if (PAY) {
+#pragma unroll
+          for (int c = 0; c < NPAY; ++c)
+            if (c < pp.n) pp.out[c][g] = spay[c][PAY ? p : 0];
+        }
       }
     }
     __syncthreads();
@@ -412,9 +422,9 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 }
 
 // One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.
-template <int THREADS, int ITEMS, bool PAY>
+template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                           const uint64_t *pay_src, uint64_t *pay_out) {
+                           const PayPtrs &pp) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   uint32_t mask = (1u << nbits) - 1;
   {
@@ -424,28 +434,38 @@ static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbit
   }
   TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
   {
-    ProfScope ps(PAY ? "radix_scatter_kernel+payload" : "radix_scatter_kernel", st);
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, PAY>), dim3(g.grid), dim3(THREADS), 0, st,
+    ProfScope ps(NPAY == 0 ? "radix_scatter_kernel" : "radix_scatter_kernel+payload", st);
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY>), dim3(g.grid), dim3(THREADS), 0, st,
                        b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                       g.tiles_per_block, b.counts, pay_src, pay_out);
+                       g.tiles_per_block, b.counts, pp);
   }
 }
 
 // Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].  With
-// pay_src / pay_out the last pass also delivers pay_out[p] = pay_src[perm[p]]; *carried tells
-// whether a pass ran at all (no pass: the order is the identity and pay_out is untouched).
+// payload columns the last pass also delivers out[c][p] = src[c][perm[p]] (one column per
+// launch; more columns replay the last pass); *carried tells whether a pass ran at all (no
+// pass: the order is the identity and the outputs are untouched).
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st, const uint64_t *pay_src, uint64_t *pay_out, bool *carried) {
+                       hipStream_t st, int n_pay, const uint64_t *const *pay_src,
+                       uint64_t *const *pay_out, bool *carried) {
   int cur = 0;
   if (carried) *carried = false;
+  PayPtrs none;
+  memset(&none, 0, sizeof(none));
   for (int lo = lo_bit; lo < hi_bit; lo += 8) {
     int nbits = hi_bit - lo < 8 ? hi_bit - lo : 8;
     bool last = lo + 8 >= hi_bit;
-    if (last && pay_src && pay_out) {
-      radix_one_pass<1024, 4, true>(b, n, cur, lo, nbits, st, pay_src, pay_out);
+    if (last && n_pay > 0) {
+      for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
+        PayPtrs pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.n = n_pay - c0 < kMaxPay ? n_pay - c0 : kMaxPay;
+        for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
+        radix_one_pass<1024, 4, 1>(b, n, cur, lo, nbits, st, pp);
+      }
       if (carried) *carried = true;
     } else {
-      radix_one_pass<1024, 8, false>(b, n, cur, lo, nbits, st, nullptr, nullptr);
+      radix_one_pass<1024, 8, 0>(b, n, cur, lo, nbits, st, none);
     }
     cur ^= 1;
   }
@@ -456,8 +476,8 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
 }
 
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
-                OrderResult *res, hipStream_t st, const uint64_t *pay_src, uint64_t *pay_out,
-                bool *carried) {
+                OrderResult *res, hipStream_t st, int n_pay, const uint64_t *const *pay_src,
+                uint64_t *const *pay_out, bool *carried) {
   if (carried) *carried = false;
   res->comp = b.comp[0];
   res->perm = b.idx[0];
@@ -470,7 +490,7 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   TMP_CHECK_HIP(hipGetLastError());
   if (sorted == 1) return TMP_OK;
   return order_radix_passes(b, s.n, sorted == 2 ? lay.key_shift() : lay.low_bits, lay.total_bits(), res, st,
-                            pay_src, pay_out, carried);
+                            n_pay, pay_src, pay_out, carried);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,

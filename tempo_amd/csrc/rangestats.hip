@@ -578,7 +578,9 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   // the metric column rides along with the last radix pass; if no pass runs the rows are
   // already in order and the column is used where it is
   bool carried = false;
-  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, (const uint64_t *)a->x, p.xs, &carried));
+  const uint64_t *pay_src[1] = {(const uint64_t *)a->x};
+  uint64_t *pay_out[1] = {p.xs};
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
   const T *xs = carried ? (const T *)p.xs : (const T *)a->x;
   RsOut<T> o;
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;

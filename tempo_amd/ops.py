@@ -107,6 +107,83 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
     return idx[:, 0], idx[:, 1:].t(), missing
 
 
+def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
+                    skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
+                    ts_partition_val=None, fraction=0.5):
+    """Fused AS-OF join: the joined table itself, in (key, ts) order, written with streaming
+    accesses only (the payload columns ride along with the last radix pass of their table).
+
+    left_cols / right_cols: lists of 8-byte-element device columns (float64 / int64);
+    right_col_masks[c]: uint8 validity of right column c or None.  Returns dict(perm, key, ts,
+    left=[columns], right=[(column, valid uint8)], missing=int32[1 + n_masks], mask_of=[...]).
+    """
+    nL, nR = ts_l.numel(), ts_r.numel()
+    dev = ts_l.device
+    _dev(ts_l, torch.int64, "ts_l")
+    _dev(ts_r, torch.int64, "ts_r")
+    _dev(key_l, torch.int32, "key_l", nL)
+    _dev(key_r, torch.int32, "key_r", nR)
+    _dev(seq_r, torch.int64, "seq_r", nR)
+    _dev(seq_r_valid, torch.uint8, "seq_r_valid", nR)
+    if len(left_cols) > _lib.TMP_MAX_JOIN_COLS or len(right_cols) > _lib.TMP_MAX_JOIN_COLS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_JOIN_COLS} payload columns per side")
+    for i, c in enumerate(left_cols):
+        if c.element_size() != 8:
+            raise TypeError("fused join columns must have 8-byte elements")
+        _dev(c, c.dtype, f"left_cols[{i}]", nL)
+    masks, mask_of, rule, vmask = [], [], [], []
+    for i, c in enumerate(right_cols):
+        if c.element_size() != 8:
+            raise TypeError("fused join columns must have 8-byte elements")
+        _dev(c, c.dtype, f"right_cols[{i}]", nR)
+        m = right_col_masks[i]
+        if m is None:
+            mask_of.append(-1); rule.append(-1); vmask.append(-1)
+            continue
+        _dev(m, torch.uint8, f"right_col_masks[{i}]", nR)
+        slot = next((k for k, mm in enumerate(masks) if mm.data_ptr() == m.data_ptr()), None)
+        if slot is None:
+            slot = len(masks)
+            masks.append(m)
+        mask_of.append(slot)
+        rule.append(slot if skip_nulls else -1)
+        vmask.append(-1 if skip_nulls else slot)
+    if len(masks) > _lib.TMP_MAX_MASKS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_MASKS} nullable right columns per call")
+    perm = torch.empty(nL, dtype=torch.int32, device=dev)
+    key_s = torch.empty(nL, dtype=torch.int32, device=dev)
+    ts_s = torch.empty(nL, dtype=torch.int64, device=dev)
+    missing = torch.empty(1 + len(masks), dtype=torch.int32, device=dev)
+    out_left = [torch.empty(nL, dtype=c.dtype, device=dev) for c in left_cols]
+    out_right = [torch.empty(nL, dtype=c.dtype, device=dev) for c in right_cols]
+    out_valid = [torch.empty(nL, dtype=torch.uint8, device=dev) for _ in right_cols]
+    skew = ts_partition_val is not None
+    a = AsofArgs()
+    a.n_left, a.n_right = nL, nR
+    a.key_left, a.ts_left, a.key_right, a.ts_right = _p(key_l), _p(ts_l), _p(key_r), _p(ts_r)
+    a.seq_right, a.seq_right_valid = _p(seq_r), _p(seq_r_valid)
+    a.n_keys, a.ts_is_seconds, a.n_masks = int(n_keys), int(bool(ts_is_seconds)), len(masks)
+    mask_ptrs = ptr_array([m.data_ptr() for m in masks])
+    a.masks = mask_ptrs
+    a.skew = int(skew)
+    a.v_is_int = int(skew and isinstance(ts_partition_val, int))
+    a.ts_partition_val = float(ts_partition_val) if skew else 0.0
+    a.one_minus_fraction = float(1 - fraction)
+    a.out_idx, a.out_missing = None, _p(missing)
+    a.sorted_output, a.out_perm, a.out_key, a.out_ts = 1, _p(perm), _p(key_s), _p(ts_s)
+    keep = [ptr_array([c.data_ptr() for c in left_cols]), ptr_array([c.data_ptr() for c in out_left]),
+            ptr_array([c.data_ptr() for c in right_cols]), ptr_array([c.data_ptr() for c in out_right]),
+            ptr_array([c.data_ptr() for c in out_valid]), (C.c_int32 * max(len(rule), 1))(*rule),
+            (C.c_int32 * max(len(vmask), 1))(*vmask)]
+    a.n_left_cols, a.left_cols, a.out_left_cols = len(left_cols), keep[0], keep[1]
+    a.n_right_cols, a.right_cols, a.out_right_cols, a.out_right_valid = len(right_cols), keep[2], keep[3], keep[4]
+    a.right_col_rule, a.right_col_valid = keep[5], keep[6]
+    ws = _workspace(lib().tmp_asof_join_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_asof_join(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_asof_join")
+    return dict(perm=perm, key=key_s, ts=ts_s, left=out_left, right=list(zip(out_right, out_valid)),
+                missing=missing, mask_of=mask_of)
+
+
 def gather(src, idx, src_valid=None, want_valid=True):
     """out[i] = src[idx[i]] (0 / invalid where idx[i] < 0 or the source is NULL)."""
     n = idx.numel()

@@ -182,3 +182,42 @@ def test_asof_sorted_output_mode(orc, ops):
                                                           17, sorted_output=True)
     assert (row.cpu().numpy() == -1).all() and np.array_equal(perm.cpu().numpy().astype(np.int64), p)
     assert missing.cpu().numpy().tolist() == [1]
+
+
+@pytest.mark.parametrize("skip_nulls,order", [(True, "random"), (False, "random"), (True, "time"), (True, "sorted")])
+def test_asof_fused_table(orc, ops, skip_nulls, order):
+    """The fused join (payload carried through the sort) equals oracle indices + a plain take."""
+    rng = np.random.default_rng(44)
+    nL, nR, nk = 90_000, 60_000, 23
+    key_l, ts_l, key_r, ts_r, _, _, masks = _make(rng, nL, nR, nk, 1800 * 1_000_000, 1000, 2, 0.15, False)
+    if order == "time":
+        o = np.argsort(ts_l, kind="stable"); key_l, ts_l = key_l[o], ts_l[o]
+        o = np.argsort(ts_r, kind="stable"); key_r, ts_r = key_r[o], ts_r[o]; masks = [m[o] for m in masks]
+    if order == "sorted":
+        o = np.lexsort((ts_l, key_l)); key_l, ts_l = key_l[o], ts_l[o]
+        o = np.lexsort((ts_r, key_r)); key_r, ts_r = key_r[o], ts_r[o]; masks = [m[o] for m in masks]
+    pr = rng.normal(100, 1, nL)
+    qty = rng.integers(1, 1000, nL)
+    bid, ask, vol = rng.normal(99, 1, nR), rng.normal(101, 1, nR), rng.integers(0, 10**12, nR)
+    out = ops.asof_join_table(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nk, [_dev(pr), _dev(qty)],
+                              [_dev(ts_r), _dev(bid), _dev(ask), _dev(vol)], [None, _dev(masks[0]), _dev(masks[1]), None],
+                              skip_nulls=skip_nulls)
+    idx, omiss = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None] + masks, skip_nulls=skip_nulls)
+    p = out["perm"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(p, np.lexsort((np.arange(nL), ts_l, key_l)))
+    assert np.array_equal(out["key"].cpu().numpy(), key_l[p]) and np.array_equal(out["ts"].cpu().numpy(), ts_l[p])
+    assert np.array_equal(out["left"][0].cpu().numpy(), pr[p]) and np.array_equal(out["left"][1].cpu().numpy(), qty[p])
+    src_cols = [ts_r, bid, ask, vol]
+    col_idx = [idx[0], idx[1], idx[2], idx[0]]
+    col_mask = [None, masks[0], masks[1], None]
+    for c in range(4):
+        j = col_idx[c][p]
+        ok = j >= 0
+        if col_mask[c] is not None and not skip_nulls:
+            ok = ok & (col_mask[c][np.clip(j, 0, None)] == 1)
+        vals, valid = out["right"][c]
+        assert np.array_equal(valid.cpu().numpy().astype(bool), ok), c
+        want = np.where(ok, src_cols[c][np.clip(j, 0, None)], 0)
+        assert np.array_equal(vals.cpu().numpy(), want), c
+    if skip_nulls:
+        assert out["missing"].cpu().numpy().tolist() == omiss.tolist()
