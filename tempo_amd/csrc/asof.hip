@@ -224,17 +224,27 @@ struct PackCols {
   const uint64_t *src[TMP_MAX_JOIN_COLS];
 };
 
-// rec[i][c] = src[c][i]; every column is read once, front to back.
+// rec[i][c] = src[c][i]; every column is read once, front to back.  One lane per 16-byte half
+// of a record pair of columns, so that a wave's stores cover one contiguous run.
 __global__ __launch_bounds__(kBlock) void pack_rows_kernel(PackCols pc, int64_t n, uint64_t *rec) {
+  const int pairs = pc.stride >> 1;  // stride is even here (2 or a multiple of 4)
+  const int64_t total = n * pairs;
   int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-    uint64_t *r = rec + (size_t)i * pc.stride;
-    for (int c = 0; c < pc.stride; c += 2) {  // stride is even here (2 or a multiple of 4)
-      ulonglong2 v;
-      v.x = c < pc.n ? pc.src[c][i] : 0ull;
-      v.y = c + 1 < pc.n ? pc.src[c + 1][i] : 0ull;
-      *reinterpret_cast<ulonglong2 *>(r + c) = v;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    int64_t i = pairs == 2 ? e >> 1 : e / pairs;
+    int c = (int)(e - i * pairs) * 2;
+    const uint64_t *pa, *pb;
+    if (pairs <= 2) {  // selects instead of a lane-varying index into the argument block
+      pa = c == 0 ? pc.src[0] : pc.src[2];
+      pb = c == 0 ? pc.src[1] : pc.src[3];
+    } else {
+      pa = pc.src[c];
+      pb = pc.src[c + 1];
     }
+    ulonglong2 v;
+    v.x = c < pc.n ? pa[i] : 0ull;
+    v.y = c + 1 < pc.n ? pb[i] : 0ull;
+    *reinterpret_cast<ulonglong2 *>(rec + (size_t)e * 2) = v;
   }
 }
 
@@ -526,11 +536,11 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   jc.rrec = nrc == 1 ? pr.src[0] : p.rrec;
   if (nlc >= 2) {
     pl.n = nlc; pl.stride = jc.lstride;
-    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_left, kBlock, 8192)), dim3(kBlock), st, pl, a->n_left, p.lrec);
+    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_left * (jc.lstride / 2), kBlock, 8192)), dim3(kBlock), st, pl, a->n_left, p.lrec);
   }
   if (nrc >= 2 && a->n_right > 0) {
     pr.n = nrc; pr.stride = jc.rstride;
-    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right, kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
+    TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right * (jc.rstride / 2), kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
   }
 
   if (a->n_masks > 0) {

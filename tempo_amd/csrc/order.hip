@@ -259,23 +259,43 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   if (tid < RS_RADIX) goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
   volatile uint32_t *wh = &whist[wave][0];
+  // The pairs of the next tile are requested while the current one is ranked and reordered, so
+  // that the block (the only one its CU has room for) keeps loads in flight through those phases.
+  uint64_t k[RS_ITEMS], kn[RS_ITEMS];
+  uint32_t v[RS_ITEMS], vn[RS_ITEMS];
+  {
+    int64_t base0 = (int64_t)blockIdx.x * tiles_per_block * RS_TILE;
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int64_t g = base0 + wave * (64 * RS_ITEMS) + it * 64 + lane;
+      bool valid = g < n;
+      kn[it] = valid ? kin[g] : 0ull;
+      vn[it] = valid ? vin[g] : 0u;
+    }
+  }
   for (int t = 0; t < tiles_per_block; ++t) {
     int64_t tile_base = ((int64_t)blockIdx.x * tiles_per_block + t) * RS_TILE;
     if (tile_base >= n) break;
     int tile_n = (int)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
     for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
-    uint64_t k[RS_ITEMS];
-    uint32_t v[RS_ITEMS];
     uint64_t pay[PAY ? NPAY : 1][PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-      bool valid = pos < tile_n;
-      k[it] = valid ? kin[tile_base + pos] : 0ull;
-      v[it] = valid ? vin[tile_base + pos] : 0u;
+      k[it] = kn[it];
+      v[it] = vn[it];
+    }
+    if (t + 1 < tiles_per_block) {
+      int64_t next_base = tile_base + RS_TILE;
+#pragma unroll
+      for (int it = 0; it < RS_ITEMS; ++it) {
+        int64_t g = next_base + wave * (64 * RS_ITEMS) + it * 64 + lane;
+        bool valid = g < n;
+        kn[it] = valid ? kin[g] : 0ull;
+        vn[it] = valid ? vin[g] : 0u;
+      }
     }
     if (PAY) {
 #pragma unroll
