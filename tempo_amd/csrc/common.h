@@ -152,7 +152,22 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);
 
+// floor(a / b), b > 0 expected (negative b falls through to the exact path).  For divisors up
+// to 2^40 the quotient comes from a double-precision estimate that two exact integer
+// remainder steps correct -- a handful of instructions instead of a 64-bit integer division.
 __device__ __forceinline__ int64_t floordiv_i64(int64_t a, int64_t b) {
+  if (b >= 2 && b <= (1ll << 40)) {
+    const double inv = 1.0 / (double)b;
+    // estimate: off by at most ~2^11 / b + 1 over the whole int64 range
+    int64_t q = (int64_t)floor((double)a * inv);
+    int64_t r = (int64_t)((uint64_t)a - (uint64_t)q * (uint64_t)b);  // exact: |r| < 2^52
+    int64_t q2 = (int64_t)floor((double)r * inv);                     // off by at most 1
+    q += q2;
+    r -= q2 * b;
+    if (r < 0) { --q; r += b; }
+    if (r >= b) { ++q; }
+    return q;
+  }
   int64_t q = a / b;
   if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
   return q;

@@ -73,7 +73,37 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
   int64_t pmin = INT64_MAX, pmax = INT64_MIN, smin = INT64_MAX, smax = INT64_MIN;
   int bad = 0, tbad = 0;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  int64_t first = 0;  // rows below `first` are covered by the four-rows-per-thread loop
+  if (!seq && (((uintptr_t)ts | (uintptr_t)key) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    first = n4 << 2;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += stride) {
+      longlong2 a = reinterpret_cast<const longlong2 *>(ts)[2 * c];
+      longlong2 b = reinterpret_cast<const longlong2 *>(ts)[2 * c + 1];
+      int4 k = key ? reinterpret_cast<const int4 *>(key)[c] : make_int4(0, 0, 0, 0);
+      int64_t t[4] = {a.x, a.y, b.x, b.y};
+      int32_t kk[4] = {k.x, k.y, k.z, k.w};
+      int64_t tp = c > 0 ? ts[4 * c - 1] : t[0];
+      int32_t kp = (c > 0 && key) ? key[4 * c - 1] : kk[0];
+      if (div != 1) {
+        tp = floordiv_i64(tp, div);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = floordiv_i64(t[j], div);
+      }
+      if (c == 0) tp = t[0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pmin = t[j] < pmin ? t[j] : pmin;
+        pmax = t[j] > pmax ? t[j] : pmax;
+        bool tdown = tp > t[j];
+        tbad |= tdown;
+        bad |= kp != kk[j] ? kp > kk[j] : tdown;
+        tp = t[j];
+        kp = kk[j];
+      }
+    }
+  }
+  for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
     pmin = p < pmin ? p : pmin;
     pmax = p > pmax ? p : pmax;
@@ -400,7 +430,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
   TMP_LAUNCH(range_init_kernel, dim3(1), dim3(1), st, b.range);
   if (s.n > 0) {
-    int grid = grid_for(s.n, kBlock * 8, 4096);
+    int grid = grid_for(s.n, kBlock * 16, 4096);
     TMP_LAUNCH(range_scan_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts,
                        s.prim_div, s.seq, s.seq_valid, b.range);
   }

@@ -169,3 +169,22 @@ def test_ema_time_ordered_feed(orc, ops):
     operm, oout = orc.ema(key, ts, x, None, 30, 0.2)
     assert np.array_equal(perm.cpu().numpy().astype(np.int64), operm)
     assert np.array_equal(out.cpu().numpy(), oout)
+
+
+@pytest.mark.parametrize("aligned", [True, False])
+def test_sort_order_seconds_cast_extreme_timestamps(ops, aligned):
+    """cast(ts as long) = floor(ts / 1e6) over the whole int64 range, both signs, at bucket edges."""
+    rng = np.random.default_rng(5)
+    n = 200_003
+    ts = rng.integers(-2**63, 2**63 - 1, n, dtype=np.int64, endpoint=True)
+    edges = rng.integers(-9_000_000_000_000, 9_000_000_000_000, 20_000) * 1_000_000
+    ts[:60_000] = np.concatenate([edges - 1, edges, edges + 1])
+    ts[60_000:60_004] = [np.iinfo(np.int64).min, np.iinfo(np.int64).max, -1, 0]
+    rng.shuffle(ts)
+    key = rng.integers(0, 5, n).astype(np.int32)
+    off = 0 if aligned else 1       # an odd element offset takes the row-at-a-time scan
+    kd, td = _dev(key)[off:], _dev(ts)[off:]
+    perm = ops.sort_order(kd, td, 5, floor_seconds=True).cpu().numpy().astype(np.int64)
+    key, ts = key[off:], ts[off:]
+    sec = np.floor_divide(ts, 1_000_000)
+    assert np.array_equal(perm, np.lexsort((np.arange(key.size), sec, key)))
