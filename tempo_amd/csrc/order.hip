@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, const int3
 // tile is first reordered in LDS so that global stores go out in runs of equal digit.
 // ------------------------------------------------------------------------------------------
 constexpr int RS_MAX_GRID = 1024;
-constexpr int RS_RADIX = 256;
+constexpr int RS_MAX_BITS = 9;  // widest digit; passes are 8 bits wide unless 9 saves a pass
 
 struct SortGeom {
   int grid;
@@ -203,13 +203,14 @@ static SortGeom sort_geom(int64_t n, int tile) {
   return g;
 }
 
-template <int RS_THREADS, int RS_ITEMS>
+template <int RS_THREADS, int RS_ITEMS, int RS_BITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
                                                                 uint32_t *counts) {
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
+  constexpr int RS_RADIX = 1 << RS_BITS;
   __shared__ uint32_t hist[RS_WAVES][RS_RADIX];
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
 // NPAY > 0: the pass also moves up to NPAY 8-byte payload columns, read through the row id
 // (src[row id]) and written next to the pair -- used on the last pass so that ordered copies
 // of payload columns cost no separate random gather (the scatter writes them in digit runs).
-template <int RS_THREADS, int RS_ITEMS, int NPAY>
+template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
@@ -278,13 +279,15 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   constexpr bool PAY = NPAY > 0;
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
+  constexpr int RS_RADIX = 1 << RS_BITS;
+  static_assert(RS_RADIX <= RS_THREADS, "one thread per digit");
   __shared__ uint64_t skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint64_t spay[PAY ? NPAY : 1][PAY ? RS_TILE : 1];
   __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
   __shared__ uint32_t dstart[RS_RADIX];
   __shared__ uint32_t goff[RS_RADIX];
-  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t wtot[RS_RADIX / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   if (tid < RS_RADIX) goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
@@ -423,7 +426,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
   b->comp[1] = ws.take<uint64_t>(cnt);
   b->idx[0] = ws.take<uint32_t>(cnt);
   b->idx[1] = ws.take<uint32_t>(cnt);
-  b->counts = ws.take<uint32_t>((size_t)RS_RADIX * RS_MAX_GRID);
+  b->counts = ws.take<uint32_t>(((size_t)1 << RS_MAX_BITS) * RS_MAX_GRID);
   b->range = ws.take<RangeInfo>(1);
 }
 
@@ -472,29 +475,37 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 }
 
 // One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.
-template <int THREADS, int ITEMS, int NPAY>
-static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                           const PayPtrs &pp) {
+template <int THREADS, int ITEMS, int NPAY, int BITS>
+static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
+                             const PayPtrs &pp) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   uint32_t mask = (1u << nbits) - 1;
   {
     ProfScope ps("radix_hist_kernel", st);
-    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS>), dim3(g.grid), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS>), dim3(g.grid), dim3(THREADS), 0, st,
                        b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts);
   }
-  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, RS_RADIX * g.grid);
+  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid);
   {
     ProfScope ps(NPAY == 0 ? "radix_scatter_kernel" : "radix_scatter_kernel+payload", st);
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY>), dim3(g.grid), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS>), dim3(g.grid), dim3(THREADS), 0, st,
                        b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
                        g.tiles_per_block, b.counts, pp);
   }
 }
 
-// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].  With
-// payload columns the last pass also delivers out[c][p] = src[c][perm[p]] (one column per
-// launch; more columns replay the last pass); *carried tells whether a pass ran at all (no
-// pass: the order is the identity and the outputs are untouched).
+template <int THREADS, int ITEMS, int NPAY>
+static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
+                           const PayPtrs &pp) {
+  if (nbits <= 8) radix_one_pass_t<THREADS, ITEMS, NPAY, 8>(b, n, cur, lo, nbits, st, pp);
+  else radix_one_pass_t<THREADS, ITEMS, NPAY, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp);
+}
+
+// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].  Digits are
+// 8 bits wide, or a mix of 8 and 9 where that takes one pass fewer.  With payload columns the
+// last pass also delivers out[c][p] = src[c][perm[p]] (one column per launch; more columns
+// replay the last pass); *carried tells whether a pass ran at all (no pass: the order is the
+// identity and the outputs are untouched).
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
                        hipStream_t st, int n_pay, const uint64_t *const *pay_src,
                        uint64_t *const *pay_out, bool *carried) {
@@ -502,9 +513,14 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
   if (carried) *carried = false;
   PayPtrs none;
   memset(&none, 0, sizeof(none));
-  for (int lo = lo_bit; lo < hi_bit; lo += 8) {
-    int nbits = hi_bit - lo < 8 ? hi_bit - lo : 8;
-    bool last = lo + 8 >= hi_bit;
+  const int total = hi_bit > lo_bit ? hi_bit - lo_bit : 0;
+  int passes = (total + 7) / 8;
+  if ((total + RS_MAX_BITS - 1) / RS_MAX_BITS < passes) passes = (total + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  int lo = lo_bit;
+  for (int p = 0; p < passes; ++p) {
+    // spread the bits evenly: the first (total % passes) digits are one bit wider
+    int nbits = total / passes + (p < total % passes ? 1 : 0);
+    bool last = p + 1 == passes;
     if (last && n_pay > 0) {
       for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
         PayPtrs pp;
@@ -517,6 +533,7 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
     } else {
       radix_one_pass<1024, 8, 0>(b, n, cur, lo, nbits, st, none);
     }
+    lo += nbits;
     cur ^= 1;
   }
   TMP_CHECK_HIP(hipGetLastError());
