@@ -78,6 +78,9 @@ def gen_ticks(dev, n, n_keys, seed, key_offset=0):
 
 # algorithmic bytes one launch of a kernel moves, per row it processes (every input read once,
 # every output written once)
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                "r01_bench1b_pmc_traffic.json")
+
 KERNEL_BYTES_PER_ROW = {
     "radix_scatter_kernel": 24.0,     # (8 B sort word + 4 B row id) in and out
     "radix_hist_kernel": 8.0,         # sort word in
@@ -211,12 +214,23 @@ def main():
         dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         name, k = dom
         bpr = KERNEL_BYTES_PER_ROW.get(name)
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE and WRITE_SIZE, separate runs of this command at the default size)
+        traffic, traffic_src = None, None
+        if rows == 1_000_000_000 and args.gpus == 1 and os.path.exists(PMC_TRAFFIC_FILE):
+            with open(PMC_TRAFFIC_FILE) as f:
+                pmc = json.load(f).get(name)
+            if pmc:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(PMC_TRAFFIC_FILE, os.path.dirname(os.path.abspath(__file__)))
         if bpr is not None:
             gbs = k["rows"] * bpr / (k["ms"] * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=name, achieved=round(gbs, 1), peak=HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                            unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic,
                             launches=k["launches"], avg_launch_ms=round(k["ms"] / k["launches"], 4),
-                            bytes_per_row=bpr)
+                            bytes_per_row=bpr,
+                            algorithmic_bytes_per_launch=int(k["rows"] / k["launches"] * bpr),
+                            traffic_source=traffic_src)
         else:
             roofline = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=None, traffic=None)

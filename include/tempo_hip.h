@@ -121,8 +121,9 @@ typedef struct {
   int32_t *out_key;      /* [n_left] or NULL (sorted_output only) */
   int64_t *out_ts;       /* [n_left] or NULL (sorted_output only) */
   /* Fused payload join (sorted_output only, 8-byte element columns, HOST arrays of device
-   * pointers, at most TMP_MAX_JOIN_COLS per side).  The columns ride along with the last
-   * radix pass of their table, so the joined table is written with streaming accesses only:
+   * pointers, at most TMP_MAX_JOIN_COLS per side).  The merge writes the joined table itself,
+   * every store streaming; a side with several payload columns is first packed into row
+   * records so that a joined row costs one random read per side:
    *   out_left_cols[c][p]  = left_cols[c][out_perm[p]]
    *   out_right_cols[c][p] = right_cols[c][j], j = the right row chosen by right_col_rule[c]
    *                          (-1: last visible row; m: last visible row with mask m valid)
