@@ -81,6 +81,18 @@ def gen_ticks(dev, n, n_keys, seed, key_offset=0):
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                                 "r01_bench1b_pmc_traffic.json")
 
+COPY_CEILING_FILE = os.path.join(os.path.dirname(PMC_TRAFFIC_FILE), "r01_copy_ceiling.json")
+
+
+def copy_ceiling():
+    """Measured device-to-device copy rate (GB/s, read + write) of an MI355X, from the committed
+    run of tools/copy_ceiling.py: the practical bound beside the nominal 8 TB/s peak."""
+    if not os.path.exists(COPY_CEILING_FILE):
+        return None
+    with open(COPY_CEILING_FILE) as f:
+        return json.load(f).get("copy_16GiB_GBps")
+
+
 KERNEL_BYTES_PER_ROW = {
     "radix_scatter_kernel": 24.0,     # (8 B sort word + 4 B row id) in and out
     "radix_hist_kernel": 8.0,         # sort word in
@@ -230,7 +242,7 @@ def main():
                             launches=k["launches"], avg_launch_ms=round(k["ms"] / k["launches"], 4),
                             bytes_per_row=bpr,
                             algorithmic_bytes_per_launch=int(k["rows"] / k["launches"] * bpr),
-                            traffic_source=traffic_src)
+                            traffic_source=traffic_src, copy_ceiling=copy_ceiling())
         else:
             roofline = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=None, traffic=None)
