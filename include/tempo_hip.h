@@ -308,6 +308,45 @@ int tmp_resample(const tmp_resample_args *a, void *workspace, size_t workspace_b
                  void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * withGroupedStats: mean / count / min / max / sum / stddev per (key, tumbling bucket).
+ *
+ * Replaces groupBy(partitionCols, window(ts_col, "<n> <unit>")).agg(mean, count, min, max,
+ * sum, stddev) of python/tempo/tsdf.py:723-759 (the bucket is resample.py's: epoch aligned,
+ * start = ts - ((ts mod dur) + dur) mod dur).  Buckets come back ordered by (key, start);
+ * *out_count receives their number.  Per column c and bucket b (index c*n + b):
+ *   out_n      number of non-NULL values (Spark count)
+ *   out_mean   sum as double / out_n                     NULL when out_n == 0
+ *   out_min / out_max / out_sum  8-byte cells of the column's own type (int64 sums wrap)
+ *                                                        NULL when out_n == 0
+ *   out_stddev sample standard deviation                 NULL when out_n < 2
+ * NULLs are not flagged separately: out_n says which cells are NULL.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int64_t dur_us;
+  int32_t n_cols;
+  const void *const *cols;   /* HOST array of n_cols device pointers (double or int64 columns) */
+  const int32_t *col_is_i64; /* host */
+  const uint8_t *const *col_valid;
+  int32_t *out_key;   /* [n] capacity */
+  int64_t *out_start; /* [n] */
+  double *out_mean;   /* [n_cols][n] */
+  int64_t *out_n;     /* [n_cols][n] */
+  void *out_min;      /* [n_cols][n] 8-byte cells */
+  void *out_max;
+  void *out_sum;
+  double *out_stddev; /* [n_cols][n] */
+  int64_t *out_count; /* device scalar */
+} tmp_grouped_stats_args;
+
+size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args *a);
+int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Key shuffle, device side: Exchange hashpartitioning(partitionCols).
  *
  * Replaces the shuffle that Window.partitionBy / groupBy imply (tsdf.py:121, :571,

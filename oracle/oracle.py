@@ -178,3 +178,41 @@ def resample(key, ts, dur_us, func, cols, cols_valid):
     assert nb >= 0
     return dict(n=int(nb), key=out_key[:nb], start=out_start[:nb], f64=out_f64[:k, :nb],
                 i64=out_i64[:k, :nb], valid=out_valid[:k, :nb], row=out_row[:nb], is_i64=is_i64)
+
+
+def grouped_stats(key, ts, dur_us, cols, cols_valid):
+    """withGroupedStats core.  cols: list of float64 or int64 arrays.  Returns dict with arrays of
+    shape [n_cols][n_buckets]: mean, count, min, max, sum (min/max/sum as raw 8-byte cells viewed
+    per column type via cell()), stddev."""
+    key, ts = _i32(key), _i64(ts)
+    n = len(ts)
+    cc, is_i64 = [], []
+    for c in cols:
+        if np.issubdtype(np.asarray(c).dtype, np.integer):
+            cc.append(_i64(c)); is_i64.append(1)
+        else:
+            cc.append(_f64(c)); is_i64.append(0)
+    vv = [_u8(v) for v in cols_valid]
+    k = len(cc)
+    cap = max(n, 1)
+    out_key = np.zeros(cap, np.int32)
+    out_start = np.zeros(cap, np.int64)
+    mean = np.zeros((max(k, 1), cap))
+    cnt = np.zeros((max(k, 1), cap), np.int64)
+    mn = np.zeros((max(k, 1), cap), np.int64)
+    mx = np.zeros((max(k, 1), cap), np.int64)
+    sm = np.zeros((max(k, 1), cap), np.int64)
+    sd = np.zeros((max(k, 1), cap))
+    flags = (C.c_int * max(k, 1))(*is_i64)
+    fn = lib().orc_grouped_stats
+    fn.restype = C.c_int64
+    nb = fn(C.c_int64(n), _p(key), _p(ts), C.c_int64(int(dur_us)), C.c_int(k), _ptr_array(cc), flags,
+            _ptr_array(vv), _p(out_key), _p(out_start), _p(mean), _p(cnt), _p(mn), _p(mx), _p(sm), _p(sd))
+    assert nb >= 0
+
+    def cell(a, c):
+        return a[c, :nb] if is_i64[c] else a[c, :nb].view(np.float64)
+
+    return dict(n=int(nb), key=out_key[:nb], start=out_start[:nb], mean=mean[:k, :nb], count=cnt[:k, :nb],
+                min=[cell(mn, c) for c in range(k)], max=[cell(mx, c) for c in range(k)],
+                sum=[cell(sm, c) for c in range(k)], stddev=sd[:k, :nb], is_i64=is_i64)

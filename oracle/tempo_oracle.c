@@ -517,3 +517,74 @@ i64 orc_resample(i64 n, const i32 *key, const i64 *ts, i64 dur_us, int func, int
   free(perm); free(start);
   return nb;
 }
+
+/* ------------------------------------------------------------------ withGroupedStats
+ * python/tempo/tsdf.py:723-759: groupBy(partitionCols, window(ts, "<n> <unit>")).agg(mean, count,
+ * min, max, sum, stddev) per metric.  Same bucket as resample.  Per bucket, values in (key, ts)
+ * order (stable): count of non-NULLs; Average = running double sum / count; Min / Max with NaN
+ * greatest; Sum in the column's type (long sums wrap); stddev_samp by CentralMomentAgg's
+ * update (n, avg, m2), NULL for fewer than two values.  Cells: out[c*cap + b].
+ * Returns the number of buckets or -1.
+ */
+i64 orc_grouped_stats(i64 n, const i32 *key, const i64 *ts, i64 dur_us, int n_cols,
+                      const void *const *cols, const int *col_is_i64, const u8 *const *col_valid,
+                      i32 *out_key, i64 *out_start, double *out_mean, i64 *out_n, void *out_min,
+                      void *out_max, void *out_sum, double *out_stddev) {
+  i64 *perm = (i64 *)malloc((size_t)(n ? n : 1) * sizeof(i64));
+  i64 *start = (i64 *)malloc((size_t)(n ? n : 1) * sizeof(i64));
+  if (!perm || !start) { free(perm); free(start); return -1; }
+  for (i64 i = 0; i < n; ++i) {
+    i64 m = ((ts[i] % dur_us) + dur_us) % dur_us;
+    start[i] = ts[i] - m;
+    perm[i] = i;
+  }
+  wctx ctx = {key, ts, NULL, NULL};
+  if (stable_sort_idx(perm, n, wcmp, &ctx)) { free(perm); free(start); return -1; }
+  i64 nb = 0, cap = n, p = 0;
+  while (p < n) {
+    i64 q = p, r0 = perm[p];
+    while (q < n && (!key || key[perm[q]] == key[r0]) && start[perm[q]] == start[r0]) ++q;
+    out_key[nb] = key ? key[r0] : 0;
+    out_start[nb] = start[r0];
+    for (int k = 0; k < n_cols; ++k) {
+      const u8 *valid = col_valid ? col_valid[k] : NULL;
+      i64 cnt = 0, best_lo = -1, best_hi = -1;
+      double s = 0.0, avg = 0.0, m2 = 0.0, nn = 0.0;
+      unsigned long long isum = 0;
+      for (i64 j = p; j < q; ++j) {
+        i64 r = perm[j];
+        if (valid && !valid[r]) continue;
+        double v = col_is_i64[k] ? (double)((const i64 *)cols[k])[r] : ((const double *)cols[k])[r];
+        ++cnt;
+        s += v;
+        if (col_is_i64[k]) isum += (unsigned long long)((const i64 *)cols[k])[r];
+        nn += 1.0;
+        double delta = v - avg, delta_n = delta / nn;
+        avg += delta_n;
+        m2 += delta * (delta - delta_n);
+        if (best_lo < 0) { best_lo = r; best_hi = r; }
+        else {
+          if (cmp_cell(cols[k], col_is_i64[k], NULL, r, best_lo) < 0) best_lo = r;
+          if (cmp_cell(cols[k], col_is_i64[k], NULL, r, best_hi) > 0) best_hi = r;
+        }
+      }
+      i64 o = (i64)k * cap + nb;
+      out_n[o] = cnt;
+      out_mean[o] = cnt ? s / (double)cnt : 0.0;
+      out_stddev[o] = cnt > 1 ? sqrt(m2 / (nn - 1.0)) : 0.0;
+      if (col_is_i64[k]) {
+        ((i64 *)out_min)[o] = cnt ? ((const i64 *)cols[k])[best_lo] : 0;
+        ((i64 *)out_max)[o] = cnt ? ((const i64 *)cols[k])[best_hi] : 0;
+        ((i64 *)out_sum)[o] = cnt ? (i64)isum : 0;
+      } else {
+        ((double *)out_min)[o] = cnt ? ((const double *)cols[k])[best_lo] : 0.0;
+        ((double *)out_max)[o] = cnt ? ((const double *)cols[k])[best_hi] : 0.0;
+        ((double *)out_sum)[o] = cnt ? s : 0.0;
+      }
+    }
+    ++nb;
+    p = q;
+  }
+  free(perm); free(start);
+  return nb;
+}

@@ -71,6 +71,15 @@ class ResampleArgs(C.Structure):
                 ("out_count", _vp)]
 
 
+class GroupedStatsArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("dur_us", C.c_int64), ("n_cols", C.c_int32), ("cols", C.POINTER(_vp)),
+                ("col_is_i64", C.POINTER(C.c_int32)), ("col_valid", C.POINTER(_vp)),
+                ("out_key", _vp), ("out_start", _vp), ("out_mean", _vp), ("out_n", _vp),
+                ("out_min", _vp), ("out_max", _vp), ("out_sum", _vp), ("out_stddev", _vp),
+                ("out_count", _vp)]
+
+
 class PartitionArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_parts", C.c_int32), ("out_perm", _vp),
                 ("out_counts", _vp)]
@@ -95,6 +104,8 @@ SYMBOLS = {
     "tmp_lookback": _OP(LookbackArgs),
     "tmp_resample_workspace_bytes": _WS(ResampleArgs),
     "tmp_resample": _OP(ResampleArgs),
+    "tmp_grouped_stats_workspace_bytes": _WS(GroupedStatsArgs),
+    "tmp_grouped_stats": _OP(GroupedStatsArgs),
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),

@@ -244,6 +244,116 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_
   }
 }
 
+// withGroupedStats: one wave per bucket; per column a first sweep for count / sum / min / max
+// and a second one, around the mean just found, for the sum of squared deviations.
+struct StatsOut {
+  double *mean;
+  int64_t *n;
+  uint64_t *mn;
+  uint64_t *mx;
+  uint64_t *sum;
+  double *stddev;
+};
+
+__global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t *perm,
+                                                                  const uint32_t *bstart,
+                                                                  const int64_t *count, int n_cols,
+                                                                  ColPtrs cols, int64_t cap,
+                                                                  StatsOut o) {
+  const int64_t nb = *count;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
+    const int64_t lo = bstart[b], hi = bstart[b + 1];
+    for (int k = 0; k < n_cols; ++k) {
+      const uint8_t *valid = cols.valid[k];
+      const bool is_i = cols.is_i64[k];
+      const int64_t *ci = (const int64_t *)cols.col[k];
+      const double *cd = (const double *)cols.col[k];
+      double sum = 0.0, dmn = 0.0, dmx = 0.0;
+      uint64_t isum = 0;
+      int64_t imn = 0, imx = 0, cnt = 0;
+      bool have = false;
+      for (int64_t j = lo + lane; j < hi; j += 64) {
+        uint32_t r = perm[j];
+        if (valid && !valid[r]) continue;
+        ++cnt;
+        if (is_i) {
+          int64_t v = ci[r];
+          sum += (double)v;
+          isum += (uint64_t)v;
+          if (!have || v < imn) imn = v;
+          if (!have || v > imx) imx = v;
+        } else {
+          double v = cd[r];
+          sum += v;
+          if (!have || dlt(v, dmn)) dmn = v;
+          if (!have || dlt(dmx, v)) dmx = v;
+        }
+        have = true;
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        double s2 = __shfl_down(sum, off, 64);
+        uint64_t u2 = __shfl_down(isum, off, 64);
+        int64_t c2 = __shfl_down(cnt, off, 64);
+        double a2 = __shfl_down(dmn, off, 64), b2 = __shfl_down(dmx, off, 64);
+        int64_t p2 = __shfl_down(imn, off, 64), q2 = __shfl_down(imx, off, 64);
+        int h2 = __shfl_down((int)have, off, 64);
+        sum += s2;
+        isum += u2;
+        cnt += c2;
+        if (h2) {
+          if (is_i) {
+            if (!have || p2 < imn) imn = p2;
+            if (!have || q2 > imx) imx = q2;
+          } else {
+            if (!have || dlt(a2, dmn)) dmn = a2;
+            if (!have || dlt(dmx, b2)) dmx = b2;
+          }
+          have = true;
+        }
+      }
+      const int64_t n = __shfl(cnt, 0, 64);
+      const double total = __shfl(sum, 0, 64);
+      const double mean = n > 0 ? total / (double)n : 0.0;
+      double acc = 0.0, lin = 0.0;
+      if (n > 1) {
+        for (int64_t j = lo + lane; j < hi; j += 64) {
+          uint32_t r = perm[j];
+          if (valid && !valid[r]) continue;
+          double d = (is_i ? (double)ci[r] : cd[r]) - mean;
+          acc += d * d;
+          lin += d;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          acc += __shfl_down(acc, off, 64);
+          lin += __shfl_down(lin, off, 64);
+        }
+      }
+      if (lane == 0) {
+        const int64_t at = (int64_t)k * cap + b;
+        o.n[at] = n;
+        o.mean[at] = mean;
+        double sd = 0.0;
+        if (n > 1) {
+          double m2 = acc - lin * lin / (double)n;
+          sd = m2 != m2 ? m2 : sqrt((m2 < 0.0 ? 0.0 : m2) / (double)(n - 1));
+        }
+        o.stddev[at] = sd;
+        if (is_i) {
+          o.mn[at] = n > 0 ? (uint64_t)imn : 0ull;
+          o.mx[at] = n > 0 ? (uint64_t)imx : 0ull;
+          o.sum[at] = n > 0 ? isum : 0ull;
+        } else {
+          o.mn[at] = n > 0 ? (uint64_t)__double_as_longlong(dmn) : 0ull;
+          o.mx[at] = n > 0 ? (uint64_t)__double_as_longlong(dmx) : 0ull;
+          o.sum[at] = n > 0 ? (uint64_t)__double_as_longlong(total) : 0ull;
+        }
+      }
+    }
+  }
+}
+
 struct RbPlan {
   OrderBuffers ob;
   uint32_t *block_counts;
@@ -251,9 +361,9 @@ struct RbPlan {
   int nblocks;
 };
 
-static void rb_plan(const tmp_resample_args *a, Workspace &ws, RbPlan *p) {
-  order_plan(a->n, ws, &p->ob);
-  size_t cnt = (size_t)(a->n > 0 ? a->n : 1);
+static void rb_plan(int64_t n, Workspace &ws, RbPlan *p) {
+  order_plan(n, ws, &p->ob);
+  size_t cnt = (size_t)(n > 0 ? n : 1);
   p->nblocks = (int)((cnt + RB_ROWS - 1) / RB_ROWS);
   p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
   p->bstart = ws.take<uint32_t>(cnt + 1);
@@ -267,7 +377,7 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a, ws, &p);
+  rb_plan(a->n, ws, &p);
   return ws.off;
 }
 
@@ -293,7 +403,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a, ws, &p);
+  rb_plan(a->n, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -322,6 +432,66 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   } else {
     TMP_LAUNCH(bucket_pick_kernel, dim3(grid_for(a->n, RB_THREADS * 4, 8192)), dim3(RB_THREADS), st, res.comp,
                res.perm, lay, p.bstart, a->out_count, a->func, a->n_cols, cp, a->out_row);
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
+
+extern "C" size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  RbPlan p;
+  rb_plan(a->n, ws, &p);
+  return ws.off;
+}
+
+extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_grouped_stats: null args");
+  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31) - 1, TMP_EINVAL,
+              "tmp_grouped_stats: row count must be in [0, 2^31-1)");
+  TMP_REQUIRE(a->dur_us > 0, TMP_EINVAL, "tmp_grouped_stats: dur_us must be positive");
+  TMP_REQUIRE(a->n_cols >= 0 && a->n_cols <= TMP_MAX_COLS, TMP_EINVAL,
+              "tmp_grouped_stats: n_cols must be in [0, %d]", TMP_MAX_COLS);
+  TMP_REQUIRE(a->out_count, TMP_EINVAL, "tmp_grouped_stats: out_count is null");
+  hipStream_t st = (hipStream_t)stream;
+  TMP_CHECK_HIP(hipMemsetAsync(a->out_count, 0, sizeof(int64_t), st));
+  if (a->n == 0) return TMP_OK;
+  TMP_REQUIRE(a->ts && a->out_key && a->out_start, TMP_EINVAL, "tmp_grouped_stats: null pointer");
+  TMP_REQUIRE(a->n_cols == 0 || (a->cols && a->col_is_i64 && a->col_valid && a->out_mean && a->out_n &&
+                                 a->out_min && a->out_max && a->out_sum && a->out_stddev),
+              TMP_EINVAL, "tmp_grouped_stats: column or output arrays missing");
+  Workspace ws(workspace, workspace_bytes);
+  RbPlan p;
+  rb_plan(a->n, ws, &p);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
+  OrderSpec s;
+  memset(&s, 0, sizeof(s));
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1;
+  Layout lay;
+  OrderResult res;
+  TMP_TRY(order_single(s, p.ob, &lay, &res, st));
+  ColPtrs cp;
+  memset(&cp, 0, sizeof(cp));
+  for (int k = 0; k < a->n_cols; ++k) {
+    TMP_REQUIRE(a->cols[k] != nullptr, TMP_EINVAL, "tmp_grouped_stats: column %d is null", k);
+    cp.col[k] = a->cols[k];
+    cp.valid[k] = a->col_valid[k];
+    cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
+  }
+  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+             p.block_counts);
+  TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
+             p.bstart, a->n);
+  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+             p.block_counts, p.bstart, a->out_key, a->out_start);
+  if (a->n_cols > 0) {
+    StatsOut o;
+    o.mean = a->out_mean; o.n = a->out_n; o.mn = (uint64_t *)a->out_min; o.mx = (uint64_t *)a->out_max;
+    o.sum = (uint64_t *)a->out_sum; o.stddev = a->out_stddev;
+    TMP_LAUNCH(bucket_stats_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
+               p.bstart, a->out_count, a->n_cols, cp, a->n, o);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

@@ -337,6 +337,53 @@ def resample(key, ts, n_keys, dur_us, func, cols, cols_valid):
                 i64=out_i64[:, :nb], valid=out_valid[:, :nb], row=out_row[:nb], is_i64=is_i64)
 
 
+def grouped_stats(key, ts, n_keys, dur_us, cols, cols_valid):
+    """withGroupedStats core (python/tempo/tsdf.py:723-759).  cols: float64 or int64 device
+    tensors.  Returns dict(n, key, start, mean, count, min, max, sum, stddev); the per-column
+    entries are lists of tensors of length n (min / max / sum in the column's own type)."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    if len(cols) > _lib.TMP_MAX_COLS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_COLS} columns per call")
+    is_i64 = []
+    for i, c in enumerate(cols):
+        if c.dtype not in (torch.float64, torch.int64):
+            raise TypeError("grouped_stats columns must be float64 or int64")
+        _dev(c, c.dtype, f"cols[{i}]", n)
+        _dev(cols_valid[i], torch.uint8, f"cols_valid[{i}]", n)
+        is_i64.append(int(c.dtype == torch.int64))
+    k, cap = len(cols), max(n, 1)
+    out_key = torch.empty(cap, dtype=torch.int32, device=dev)
+    out_start = torch.empty(cap, dtype=torch.int64, device=dev)
+    mean = torch.empty((max(k, 1), cap), dtype=torch.float64, device=dev)
+    cnt = torch.empty((max(k, 1), cap), dtype=torch.int64, device=dev)
+    mn = torch.empty((max(k, 1), cap), dtype=torch.int64, device=dev)
+    mx = torch.empty_like(mn)
+    sm = torch.empty_like(mn)
+    sd = torch.empty_like(mean)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = _lib.GroupedStatsArgs()
+    a.n, a.key, a.n_keys, a.ts, a.dur_us, a.n_cols = n, _p(key), int(n_keys), _p(ts), int(dur_us), k
+    keep = [ptr_array([c.data_ptr() for c in cols]), (C.c_int32 * max(k, 1))(*is_i64),
+            ptr_array([0 if v is None else v.data_ptr() for v in cols_valid])]
+    a.cols, a.col_is_i64, a.col_valid = keep
+    a.out_key, a.out_start, a.out_mean, a.out_n = _p(out_key), _p(out_start), _p(mean), _p(cnt)
+    a.out_min, a.out_max, a.out_sum, a.out_stddev, a.out_count = _p(mn), _p(mx), _p(sm), _p(sd), _p(count)
+    ws = _workspace(lib().tmp_grouped_stats_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_grouped_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_grouped_stats")
+    nb = int(count.item())
+
+    def cell(t, c):
+        return t[c, :nb] if is_i64[c] else t[c, :nb].view(torch.float64)
+
+    return dict(n=nb, key=out_key[:nb], start=out_start[:nb], mean=[mean[c, :nb] for c in range(k)],
+                count=[cnt[c, :nb] for c in range(k)], min=[cell(mn, c) for c in range(k)],
+                max=[cell(mx, c) for c in range(k)], sum=[cell(sm, c) for c in range(k)],
+                stddev=[sd[c, :nb] for c in range(k)], is_i64=is_i64)
+
+
 def hash_partition(key, n_parts):
     """Bucket rows by owner = hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts])."""
     n = key.numel()

@@ -261,6 +261,62 @@ class TSDF:
             df[name] = vals
         return TSDF(df, self.ts_col, self.partitionCols)
 
+    def withGroupedStats(self, metricCols=[], freq=None):
+        """mean/count/min/max/sum/stddev of every metric column per partition key and tumbling
+        `freq` bucket (python/tempo/tsdf.py:723-759).  Columns come back as the reference orders
+        them: partition columns, the six statistics per metric, then ts_col (= bucket start)."""
+        if not metricCols:
+            prohibited_cols = [self.ts_col.lower()] + [pc.lower() for pc in self.partitionCols]
+            metricCols = [c for c in self.df.columns
+                          if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+        dur_us, _, _ = rs.bucket_duration_us(self, freq)
+        ts_series = self.df[self.ts_col]
+        if not pd.api.types.is_datetime64_any_dtype(ts_series.dtype):
+            raise TypeError("withGroupedStats needs a timestamp ts_col (Spark's window() does)")
+        (key,), n_keys = col.encode_keys([self.df], self.partitionCols)
+        ts, _ = col.ts_to_int64(ts_series)
+        key_d, ts_d = col.to_dev(key), col.to_dev(ts)
+        xs, xv, kinds = [], [], []
+        for metric in metricCols:
+            x, v, kind = col.numeric_to_device(self.df[metric])
+            xs.append(x)
+            xv.append(v)
+            kinds.append(kind)
+        r = ops.grouped_stats(key_d, ts_d, n_keys, dur_us, xs, xv)
+        nb = r["n"]
+        # one representative row per bucket carries the partition column values
+        rep = ops.resample(key_d, ts_d, n_keys, dur_us, rs.floor, [], [])["row"].cpu().numpy()
+        first = self.df.iloc[rep].reset_index(drop=True)
+        out = {c: first[c] for c in self.partitionCols}
+        for i, metric in enumerate(metricCols):
+            s = self.df[metric]
+            cnt = r["count"][i].cpu().numpy()
+            ok, sd_ok = cnt > 0, cnt > 1
+            mn, mx, sm = (r[k][i].cpu().numpy() for k in ("min", "max", "sum"))
+            out['mean_' + metric] = pd.Series(np.where(ok, r["mean"][i].cpu().numpy(), np.nan))
+            out['count_' + metric] = pd.Series(cnt)
+            if kinds[i] == "i64":
+                as_in = (lambda v: pd.Series(v).astype(s.dtype) if ok.all()
+                         else pd.Series(v).astype("Int64").where(ok, pd.NA))
+                out['min_' + metric] = as_in(mn)
+                out['max_' + metric] = as_in(mx)
+                out['sum_' + metric] = pd.Series(sm) if ok.all() else pd.Series(sm).astype("Int64").where(ok, pd.NA)
+            else:
+                out['min_' + metric] = pd.Series(np.where(ok, mn, np.nan).astype(s.dtype))
+                out['max_' + metric] = pd.Series(np.where(ok, mx, np.nan).astype(s.dtype))
+                out['sum_' + metric] = pd.Series(np.where(ok, sm, np.nan))
+            out['stddev_' + metric] = pd.Series(np.where(sd_ok, r["stddev"][i].cpu().numpy(), np.nan))
+        starts = r["start"].cpu().numpy()
+        tz = getattr(ts_series.dtype, "tz", None)
+        if tz is None:
+            out[self.ts_col] = pd.Series(starts.astype("datetime64[us]").astype(ts_series.to_numpy().dtype))
+        else:
+            out[self.ts_col] = pd.Series(pd.to_datetime(starts, unit="us", utc=True).tz_convert(tz))
+        names = list(out)
+        summary = (pd.concat([out[k].reset_index(drop=True).rename(k) for k in names], axis=1) if nb
+                   else pd.DataFrame({k: out[k] for k in names}, columns=names))
+        return TSDF(summary, self.ts_col, self.partitionCols)
+
     def resample(self, freq, func=None, metricCols=None, prefix=None, fill=None):
         """Downsample to `freq` buckets with floor / min / max / mean / ceil
         (python/tempo/tsdf.py:764-776)."""

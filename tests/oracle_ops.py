@@ -78,3 +78,13 @@ def resample(key, ts, n_keys, dur_us, func, cols, cols_valid):
     r = oracle.resample(_np(key), _np(ts), dur_us, func, [_np(c) for c in cols], [_np(v) for v in cols_valid])
     return dict(n=r["n"], key=_t(r["key"]), start=_t(r["start"]), f64=_t(r["f64"]), i64=_t(r["i64"]),
                 valid=_t(r["valid"]), row=_t(r["row"], torch.int32), is_i64=r["is_i64"])
+
+
+def grouped_stats(key, ts, n_keys, dur_us, cols, cols_valid):
+    r = oracle.grouped_stats(_np(key), _np(ts), dur_us, [_np(c) for c in cols], [_np(v) for v in cols_valid])
+    k = len(cols)
+    return dict(n=r["n"], key=_t(r["key"]), start=_t(r["start"]), mean=[_t(r["mean"][c]) for c in range(k)],
+                count=[_t(r["count"][c]) for c in range(k)], min=[_t(np.ascontiguousarray(r["min"][c])) for c in range(k)],
+                max=[_t(np.ascontiguousarray(r["max"][c])) for c in range(k)],
+                sum=[_t(np.ascontiguousarray(r["sum"][c])) for c in range(k)],
+                stddev=[_t(r["stddev"][c]) for c in range(k)], is_i64=r["is_i64"])

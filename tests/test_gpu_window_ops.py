@@ -188,3 +188,47 @@ def test_sort_order_seconds_cast_extreme_timestamps(ops, aligned):
     key, ts = key[off:], ts[off:]
     sec = np.floor_divide(ts, 1_000_000)
     assert np.array_equal(perm, np.lexsort((np.arange(key.size), sec, key)))
+
+
+@pytest.mark.parametrize("seed,dur", [(0, 60_000_000), (1, 1_000_000), (2, 86_400_000_000)])
+def test_grouped_stats(orc, ops, seed, dur):
+    """withGroupedStats core against the oracle: buckets, count, min, max bit-exact (int sums too);
+    mean / double sum / stddev within 1e-9 relative."""
+    rng = np.random.default_rng(seed)
+    n, nk = 60_000, 7
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = 1_596_240_000_000_000 + rng.integers(0, 3 * 3600 * 1_000_000, n)
+    xd = 100 + np.cumsum(rng.normal(0, 0.01, n))
+    xd[rng.random(n) < 0.001] = np.nan
+    xi = rng.integers(-10**12, 10**12, n)
+    vd = (rng.random(n) > 0.05).astype(np.uint8)
+    vi = (rng.random(n) > 0.5).astype(np.uint8)
+    r = ops.grouped_stats(_dev(key), _dev(ts), nk, dur, [_dev(xd), _dev(xi), _dev(xd)], [_dev(vd), _dev(vi), None])
+    e = orc.grouped_stats(key, ts, dur, [xd, xi, xd], [vd, vi, None])
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["start"].cpu().numpy(), e["start"])
+    for c in range(3):
+        cnt = r["count"][c].cpu().numpy()
+        assert np.array_equal(cnt, e["count"][c]), c
+        ok, ok2 = cnt > 0, cnt > 1
+        for name in ("min", "max"):
+            assert np.array_equal(r[name][c].cpu().numpy()[ok], e[name][c][ok], equal_nan=True), (c, name)
+        if e["is_i64"][c]:
+            assert np.array_equal(r["sum"][c].cpu().numpy()[ok], e["sum"][c][ok])
+        else:
+            np.testing.assert_allclose(r["sum"][c].cpu().numpy()[ok], e["sum"][c][ok], rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(r["mean"][c].cpu().numpy()[ok], e["mean"][c][ok], rtol=1e-9, equal_nan=True)
+        scale = 1e12 if e["is_i64"][c] else 100.0
+        np.testing.assert_allclose(r["stddev"][c].cpu().numpy()[ok2], e["stddev"][c][ok2], rtol=1e-9,
+                                   atol=1e-12 * scale, equal_nan=True)
+
+
+def test_grouped_stats_empty_and_single_series(orc, ops):
+    e = ops.grouped_stats(None, _dev(np.zeros(0, np.int64)), 1, 60_000_000, [], [])
+    assert e["n"] == 0
+    ts = 1_596_240_000_000_000 + np.arange(10) * 30_000_000
+    x = np.arange(10, dtype=np.float64)
+    r = ops.grouped_stats(None, _dev(ts), 1, 60_000_000, [_dev(x)], [None])
+    assert r["n"] == 5 and r["count"][0].cpu().numpy().tolist() == [2] * 5
+    assert r["mean"][0].cpu().numpy().tolist() == [0.5, 2.5, 4.5, 6.5, 8.5]
+    np.testing.assert_allclose(r["stddev"][0].cpu().numpy(), np.full(5, np.sqrt(0.5)), rtol=1e-12)

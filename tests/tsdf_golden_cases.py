@@ -118,6 +118,26 @@ def case_range_stats(TSDF):
     assert_frames_equal(out.drop(columns=["trade_pr"]), exp, decimals=2)  # cast decimal(5,2), tsdf_tests.py:482-499
 
 
+def case_grouped_stats(TSDF):
+    """tsdf_tests.py:504-564."""
+    fx = _golden()["grouped_stats"]
+    df = build_df(fx["columns"], fx["data"], float32=fx["float32_columns"])
+    df["index"] = df["index"].astype(np.int32)
+    exp = build_df(fx["expected_columns"], fx["expected"])
+    out = TSDF(df, partition_cols=["symbol"]).withGroupedStats(freq=fx["freq"]).df
+    stats = ["mean_", "count_", "min_", "max_", "sum_", "stddev_"]
+    assert list(out.columns) == (["symbol"] + [s + "trade_pr" for s in stats] + [s + "index" for s in stats]
+                                 + ["event_ts"])
+    assert out["min_trade_pr"].dtype == np.float32 and out["count_trade_pr"].dtype == np.int64
+    assert out["sum_index"].tolist() == [2, 2] and out["min_index"].dtype == np.int32
+    assert out["stddev_index"].tolist() == [0.0, 0.0] and out["mean_index"].tolist() == [1.0, 1.0]
+    assert_frames_equal(out[fx["expected_columns"]], exp, decimals=2)  # cast decimal(5,2), tsdf_tests.py:546-561
+    # explicit metric list, coarser bucket: everything lands in one bucket per month
+    one = TSDF(df, partition_cols=["symbol"]).withGroupedStats(metricCols=["trade_pr"], freq="1 day").df
+    assert list(one.columns) == ["symbol"] + [s + "trade_pr" for s in stats] + ["event_ts"]
+    assert one["count_trade_pr"].tolist() == [2, 2]
+
+
 def case_resample(TSDF):
     fx = _golden()["resample"]
     df = build_df(fx["columns"], fx["data"], float32=fx["float32_columns"])
@@ -203,4 +223,4 @@ def case_errors(TSDF):
 
 
 ALL_CASES = [case_asof_basic, case_asof_skip_nulls, case_asof_sequence, case_asof_skew, case_range_stats,
-             case_resample, case_resample_fill, case_ema, case_lookback, case_errors]
+             case_grouped_stats, case_resample, case_resample_fill, case_ema, case_lookback, case_errors]
