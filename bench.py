@@ -104,8 +104,8 @@ KERNEL_BYTES_PER_ROW = {
     # row id 4 + one 32 B payload record in (the two sides have equal row counts);
     # row id 4 + key 4 + ts 8 + left payload 8 + 3 x (value 8 + flag 1) out
     "asof_merge_kernel": 123.0,
-    "lastnn_scan_kernel": 16.0,       # word 8 in, 2 x 4 B out
-    "lastnn_reduce_kernel": 8.0,
+    "lastnn_scan_kernel<false>": 16.0,       # word 8 in, 2 x 4 B out
+    "lastnn_reduce_kernel<false>": 8.0,
     "range_scan_kernel": 12.0,        # key 4 + ts 8 in
     "make_comp_kernel": 24.0,         # key 4 + ts 8 in, word 8 + id 4 out (+ mask bytes on the right side)
 }

@@ -37,6 +37,7 @@ extern "C" {
 #define TMP_EWORKSPACE (-2)   /* workspace too small */
 #define TMP_EHIP (-3)         /* HIP runtime error */
 #define TMP_EUNSUPPORTED (-4) /* valid request outside what this build supports */
+#define TMP_ECAPACITY (-5)    /* the result has more rows than the caller made room for */
 
 int tmp_abi_version(void);
 /* Thread-local text of the last error on the calling thread ("" if none). */
@@ -306,6 +307,66 @@ typedef struct {
 size_t tmp_resample_workspace_bytes(const tmp_resample_args *a);
 int tmp_resample(const tmp_resample_args *a, void *workspace, size_t workspace_bytes,
                  void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * interpolate: upsample a sampled table to a regular grid and fill the gaps.
+ *
+ * Replaces the window / explode(sequence()) plan of Interpolation.interpolate,
+ * python/tempo/interpol.py:260-378 (helpers :182-258, per-method rules :96-180, the linear
+ * expression :66-94).  Input = the sampled table (one row per key and bucket of `freq_us`, what
+ * tmp_resample returns).  In (key, ts) order every input row r yields the rows
+ *   ts[r], ts[r] + freq, ..., < next_ts[r]      next_ts = ts of the key's next row, or ts[r] + freq
+ * (the first one is the row itself, the others are "ts interpolated").  Per target column c a
+ * cell is "interpolated" when its row is, or when the input value is NULL; such cells are filled
+ * by `method`:
+ *   TMP_FILL_ZERO   0            TMP_FILL_NULL   NULL
+ *   TMP_FILL_FFILL  the key's last non-NULL value at or before r
+ *   TMP_FILL_BFILL  the next row's value (NULL when that is NULL), except that an input row
+ *                   whose own and next values are both NULL takes the key's first non-NULL
+ *                   value after it (interpol.py:152-170)
+ *   TMP_FILL_LINEAR interpol.py:74-87: between the surrounding non-NULL values for a NULL input
+ *                   row, between the row and its successor otherwise, on whole seconds
+ *                   (unix_timestamp), same fp64 operations in the same order; NULL when an end
+ *                   is missing
+ * Outputs have *out_count rows (device scalar), ordered by (key, ts).  The call first counts;
+ * when the count exceeds `capacity` nothing else is written and TMP_ECAPACITY is returned, so
+ * a caller may probe with capacity 0, read *out_count, allocate and call again.
+ *   out_src[q]  input row the output row q stems from     out_ts[q]  its timestamp
+ *   out_key[q]  its key id                                 out_ts_interp[q]  1 = generated row
+ *   out_val[c*capacity + q], out_valid[...] (0 = NULL), out_interp[...] (is_interpolated_<c>)
+ * A gap between two rows of a key that is shorter than freq_us (the input was not sampled at
+ * this frequency) is rejected with TMP_EINVAL, as Spark's sequence() rejects it.
+ */
+#define TMP_FILL_ZERO 0
+#define TMP_FILL_NULL 1
+#define TMP_FILL_BFILL 2
+#define TMP_FILL_FFILL 3
+#define TMP_FILL_LINEAR 4
+
+typedef struct {
+  int64_t n;
+  const int32_t *key; /* NULL: a single series */
+  int32_t n_keys;
+  const int64_t *ts;  /* microseconds */
+  int64_t freq_us;
+  int32_t method;
+  int32_t n_cols;     /* <= TMP_MAX_MASKS */
+  const double *const *cols;        /* HOST array of device pointers */
+  const uint8_t *const *col_valid;  /* HOST array; entries may be NULL */
+  int64_t capacity;
+  int32_t *out_src;
+  int32_t *out_key;
+  int64_t *out_ts;
+  uint8_t *out_ts_interp;
+  double *out_val;     /* [n_cols][capacity] */
+  uint8_t *out_valid;  /* [n_cols][capacity] */
+  uint8_t *out_interp; /* [n_cols][capacity] */
+  int64_t *out_count;  /* device scalar */
+} tmp_interpolate_args;
+
+size_t tmp_interpolate_workspace_bytes(const tmp_interpolate_args *a);
+int tmp_interpolate(const tmp_interpolate_args *a, void *workspace, size_t workspace_bytes,
+                    void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * withGroupedStats: mean / count / min / max / sum / stddev per (key, tumbling bucket).

@@ -216,3 +216,38 @@ def grouped_stats(key, ts, dur_us, cols, cols_valid):
     return dict(n=int(nb), key=out_key[:nb], start=out_start[:nb], mean=mean[:k, :nb], count=cnt[:k, :nb],
                 min=[cell(mn, c) for c in range(k)], max=[cell(mx, c) for c in range(k)],
                 sum=[cell(sm, c) for c in range(k)], stddev=sd[:k, :nb], is_i64=is_i64)
+
+
+FILL_CODES = {"zero": 0, "null": 1, "bfill": 2, "ffill": 3, "linear": 4}
+
+
+def interpolate(key, ts, freq_us, method, cols, cols_valid):
+    """Interpolation.interpolate on a sampled table.  cols: list of float64 arrays.  Returns dict
+    (n, src, key, ts, ts_interp, val[c], valid[c], interp[c]) in (key, ts) order."""
+    key, ts = _i32(key), _i64(ts)
+    n = len(ts)
+    cc = [_f64(c) for c in cols]
+    vv = [_u8(v) for v in cols_valid]
+    k = len(cc)
+    fn = lib().orc_interpolate
+    fn.restype = C.c_int64
+    cap = max(n, 1)
+    while True:
+        src = np.zeros(cap, np.int64)
+        okey = np.zeros(cap, np.int32)
+        ots = np.zeros(cap, np.int64)
+        tsi = np.zeros(cap, np.uint8)
+        val = np.zeros((max(k, 1), cap))
+        valid = np.zeros((max(k, 1), cap), np.uint8)
+        interp = np.zeros((max(k, 1), cap), np.uint8)
+        m = fn(C.c_int64(n), _p(key), _p(ts), C.c_int64(int(freq_us)), C.c_int(FILL_CODES[method]), C.c_int(k),
+               _ptr_array(cc), _ptr_array(vv), C.c_int64(cap), _p(src), _p(okey), _p(ots), _p(tsi), _p(val),
+               _p(valid), _p(interp))
+        if m == -3:
+            cap *= 4
+            continue
+        if m == -2:
+            raise ValueError("a gap between two rows of one key is shorter than freq")
+        assert m >= 0
+        return dict(n=int(m), src=src[:m], key=okey[:m], ts=ots[:m], ts_interp=tsi[:m], val=val[:k, :m],
+                    valid=valid[:k, :m], interp=interp[:k, :m])

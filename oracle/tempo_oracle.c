@@ -588,3 +588,95 @@ i64 orc_grouped_stats(i64 n, const i32 *key, const i64 *ts, i64 dur_us, int n_co
   free(perm); free(start);
   return nb;
 }
+
+/* ------------------------------------------------------------------ interpolate
+ * python/tempo/interpol.py:260-378 on an already sampled table (one row per key and bucket),
+ * restated column by column the way the reference builds it:
+ *   previous_timestamp = ts, next_timestamp = lead(ts) or ts + freq          (:182-195, :316-321)
+ *   per target c: ts_c = value NULL ? NULL : ts; previous_timestamp_c / next_timestamp_c =
+ *   last / first non-NULL ts_c over rows <= / >= r; previous_c / next_null_c = last / first
+ *   non-NULL value likewise; next_c = lead(value)                            (:197-258, :306-313)
+ *   explode(sequence(ts, next_timestamp - freq, freq))                       (:331-336)
+ *   is_ts_interpolated, is_interpolated_c and the fill rule per method       (:96-180, :66-94)
+ * method: 0 zero, 1 null, 2 bfill, 3 ffill, 4 linear.  Output rows ordered by (key, ts).
+ * Returns the number of output rows, -1 on allocation failure, -2 when a gap is shorter than
+ * freq (Spark's sequence() would fail), -3 when cap is too small (nothing written).
+ */
+i64 orc_interpolate(i64 n, const i32 *key, const i64 *ts, i64 freq_us, int method, int n_cols,
+                    const double *const *cols, const u8 *const *col_valid, i64 cap, i64 *out_src,
+                    i32 *out_key, i64 *out_ts, u8 *out_ts_interp, double *out_val, u8 *out_valid,
+                    u8 *out_interp) {
+  i64 *perm = (i64 *)malloc((size_t)(n ? n : 1) * sizeof(i64));
+  if (!perm) return -1;
+  for (i64 i = 0; i < n; ++i) perm[i] = i;
+  wctx ctx = {key, ts, NULL, NULL};
+  if (stable_sort_idx(perm, n, wcmp, &ctx)) { free(perm); return -1; }
+  /* size first */
+  i64 total = 0;
+  for (i64 p = 0; p < n; ++p) {
+    i64 r = perm[p];
+    int has_next = p + 1 < n && (!key || key[perm[p + 1]] == key[r]);
+    i64 next_ts = has_next ? ts[perm[p + 1]] : ts[r] + freq_us;
+    i64 stop = next_ts - freq_us;
+    if (stop < ts[r]) { free(perm); return -2; }
+    total += (stop - ts[r]) / freq_us + 1;
+  }
+  if (total > cap) { free(perm); return -3; }
+  i64 q = 0;
+  for (i64 p = 0; p < n; ++p) {
+    i64 r = perm[p];
+    int has_next = p + 1 < n && (!key || key[perm[p + 1]] == key[r]);
+    i64 next_ts = has_next ? ts[perm[p + 1]] : ts[r] + freq_us;
+    for (i64 t = ts[r]; t <= next_ts - freq_us; t += freq_us, ++q) {
+      int ts_interp = t != ts[r];
+      out_src[q] = r;
+      out_key[q] = key ? key[r] : 0;
+      out_ts[q] = t;
+      out_ts_interp[q] = (u8)ts_interp;
+      for (int c = 0; c < n_cols; ++c) {
+        const u8 *valid = col_valid ? col_valid[c] : NULL;
+        int have = !valid || valid[r];
+        int interp = ts_interp || !have;
+        /* window columns of row r */
+        i64 pj = -1, nj = -1;
+        for (i64 j = p; j >= 0 && (!key || key[perm[j]] == key[r]); --j)
+          if (!valid || valid[perm[j]]) { pj = perm[j]; break; }
+        for (i64 j = p; j < n && (!key || key[perm[j]] == key[r]); ++j)
+          if (!valid || valid[perm[j]]) { nj = perm[j]; break; }
+        int next_ok = has_next && (!valid || valid[perm[p + 1]]);
+        double v = 0.0;
+        int ok = 0;
+        if (!interp) { v = cols[c][r]; ok = 1; }
+        else if (method == 0) { v = 0.0; ok = 1; }
+        else if (method == 1) { ok = 0; }
+        else if (method == 3) { if (pj >= 0) { v = cols[c][pj]; ok = 1; } }
+        else if (method == 2) {
+          if (!next_ok && !have) { if (nj >= 0) { v = cols[c][nj]; ok = 1; } }
+          else if (next_ok) { v = cols[c][perm[p + 1]]; ok = 1; }
+        } else {
+          if (!have) {
+            if (pj >= 0 && nj >= 0) {
+              i64 tp = floordiv64(ts[pj], 1000000), den = floordiv64(ts[nj], 1000000) - tp;
+              if (den != 0) {
+                v = (cols[c][nj] - cols[c][pj]) / (double)den * (double)(floordiv64(t, 1000000) - tp) + cols[c][pj];
+                ok = 1;
+              }
+            }
+          } else if (next_ok) {
+            i64 tp = floordiv64(ts[r], 1000000), den = floordiv64(next_ts, 1000000) - tp;
+            if (den != 0) {
+              v = (cols[c][perm[p + 1]] - cols[c][r]) / (double)den * (double)(floordiv64(t, 1000000) - tp) + cols[c][r];
+              ok = 1;
+            }
+          }
+        }
+        i64 at = (i64)c * cap + q;
+        out_val[at] = ok ? v : 0.0;
+        out_valid[at] = (u8)ok;
+        out_interp[at] = (u8)interp;
+      }
+    }
+  }
+  free(perm);
+  return total;
+}

@@ -14,6 +14,7 @@ TMP_MAX_JOIN_COLS = 16
 TMP_MAX_TAPS = 1024
 TMP_MAX_FEATURES = 64
 TMP_MAX_COLS = 64
+TMP_ECAPACITY = -5
 FUNC_CODES = {"floor": 0, "min": 1, "max": 2, "mean": 3, "ceil": 4}
 
 _vp = C.c_void_p
@@ -80,6 +81,14 @@ class GroupedStatsArgs(C.Structure):
                 ("out_count", _vp)]
 
 
+class InterpolateArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("freq_us", C.c_int64), ("method", C.c_int32), ("n_cols", C.c_int32),
+                ("cols", C.POINTER(_vp)), ("col_valid", C.POINTER(_vp)), ("capacity", C.c_int64),
+                ("out_src", _vp), ("out_key", _vp), ("out_ts", _vp), ("out_ts_interp", _vp),
+                ("out_val", _vp), ("out_valid", _vp), ("out_interp", _vp), ("out_count", _vp)]
+
+
 class PartitionArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_parts", C.c_int32), ("out_perm", _vp),
                 ("out_counts", _vp)]
@@ -106,6 +115,8 @@ SYMBOLS = {
     "tmp_resample": _OP(ResampleArgs),
     "tmp_grouped_stats_workspace_bytes": _WS(GroupedStatsArgs),
     "tmp_grouped_stats": _OP(GroupedStatsArgs),
+    "tmp_interpolate_workspace_bytes": _WS(InterpolateArgs),
+    "tmp_interpolate": _OP(InterpolateArgs),
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),

@@ -51,7 +51,10 @@ static ScanGeom scan_geom(int64_t n) {
   return g;
 }
 
+// The scans below run front to back; REV mirrors the index space (row i stands for row n-1-i),
+// which turns "last set position at or before" into "first set position at or after".
 // Phase 1: per unit and mask, the last position whose bit is set (or -1).
+template <bool REV>
 __global__ __launch_bounds__(kUnitBlock) void lastnn_reduce_kernel(const uint64_t *comp, int64_t n,
                                                                    int n_masks,
                                                                    int64_t rows_per_unit, int units,
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_reduce_kernel(const uint64_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t i = base + r * 64 + lane;
-      w[r] = i < end ? comp[i] : 0ull;
+      w[r] = i < end ? comp[REV ? n - 1 - i : i] : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -117,7 +120,9 @@ __global__ __launch_bounds__(1024) void lastnn_carry_kernel(int32_t *unit_agg, i
   }
 }
 
-// Phase 3: write lastnn[m][j] = last position <= j whose mask bit m is set, or -1.
+// Phase 3: write lastnn[m][j] = last position <= j whose mask bit m is set, or -1 (REV: the
+// first position >= j, or -1).
+template <bool REV>
 __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t *comp, int64_t n,
                                                                  int n_masks,
                                                                  int64_t rows_per_unit, int units,
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t i = base + r * 64 + lane;
-      w[r] = i < end ? comp[i] : 0ull;
+      w[r] = i < end ? comp[REV ? n - 1 - i : i] : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -149,12 +154,39 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
           uint64_t bal = __ballot((w[r] >> m) & 1ull);
           uint64_t le = bal & le_mask;
           int32_t j = le ? (int32_t)(base + r * 64 + 63 - __clzll((long long)le)) : carry[m];
-          if (i < end) lastnn[(size_t)m * n + i] = j;
+          if (i < end) {
+            if (REV) lastnn[(size_t)m * n + (n - 1 - i)] = j < 0 ? -1 : (int32_t)(n - 1 - j);
+            else lastnn[(size_t)m * n + i] = j;
+          }
           if (bal) carry[m] = (int32_t)(base + r * 64 + 63 - __clzll((long long)bal));
         }
       }
     }
   }
+}
+
+size_t last_valid_scratch_ints() { return (size_t)TMP_MAX_MASKS * kUnits; }
+
+int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
+                    bool reverse, hipStream_t st) {
+  if (n <= 0 || n_masks <= 0) return TMP_OK;
+  ScanGeom g = scan_geom(n);
+  int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
+  if (reverse) {
+    TMP_LAUNCH(lastnn_reduce_kernel<true>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
+               g.rows_per_unit, g.units, unit_agg);
+    TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
+    TMP_LAUNCH(lastnn_scan_kernel<true>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
+               g.rows_per_unit, g.units, unit_agg, out);
+  } else {
+    TMP_LAUNCH(lastnn_reduce_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
+               g.rows_per_unit, g.units, unit_agg);
+    TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
+    TMP_LAUNCH(lastnn_scan_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
+               g.rows_per_unit, g.units, unit_agg, out);
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
 }
 
 // Bracket rule of tsdf.py:178-185, same IEEE operations in the same order (the library is
@@ -399,7 +431,7 @@ static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
   order_plan(a->n_right, ws, &p->rb);
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
-  p->unit_agg = ws.take<int32_t>(nm * kUnits);
+  p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());
   const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
   p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
   p->rrec = ws.take<uint64_t>(nrc >= 2 ? (size_t)rec_stride(nrc) * (size_t)a->n_right : 2);
@@ -543,15 +575,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right * (jc.rstride / 2), kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
   }
 
-  if (a->n_masks > 0) {
-    ScanGeom g = scan_geom(a->n_right);
-    int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
-    TMP_LAUNCH(lastnn_reduce_kernel, dim3(blocks), dim3(kUnitBlock), st, ro.comp,
-                       a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg);
-    TMP_LAUNCH(lastnn_carry_kernel, dim3(a->n_masks), dim3(1024), st, p.unit_agg, g.units);
-    TMP_LAUNCH(lastnn_scan_kernel, dim3(blocks), dim3(kUnitBlock), st, ro.comp,
-                       a->n_right, a->n_masks, g.rows_per_unit, g.units, p.unit_agg, p.lastnn);
-  }
+  TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, st));
   SkewParams sp;
   sp.enabled = a->skew != 0;
   sp.v_is_int = a->v_is_int;

@@ -152,6 +152,14 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);
 
+// Per mask bit m < n_masks of the sort words: out[m*n + j] = last position <= j whose bit is set
+// (reverse: first position >= j), or -1.  unit_agg: last_valid_scratch_ints() int32 of scratch.
+size_t last_valid_scratch_ints();
+int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
+                    bool reverse, hipStream_t st);
+// Exclusive scan of `total` uint32 counters in place.
+int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st);
+
 // floor(a / b), b > 0 expected (negative b falls through to the exact path).  For divisors up
 // to 2^40 the quotient comes from a double-precision estimate that two exact integer
 // remainder steps correct -- a handful of instructions instead of a 64-bit integer division.

@@ -268,6 +268,12 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
   }
 }
 
+int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
+  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, counts, total);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
+
 // NPAY > 0: the pass also moves up to NPAY 8-byte payload columns, read through the row id
 // (src[row id]) and written next to the pair -- used on the last pass so that ordered copies
 // of payload columns cost no separate random gather (the scatter writes them in digit runs).

@@ -384,6 +384,54 @@ def grouped_stats(key, ts, n_keys, dur_us, cols, cols_valid):
                 stddev=[sd[c, :nb] for c in range(k)], is_i64=is_i64)
 
 
+FILL_CODES = {"zero": 0, "null": 1, "bfill": 2, "ffill": 3, "linear": 4}
+
+
+def interpolate(key, ts, n_keys, freq_us, method, cols, cols_valid):
+    """Interpolation core (python/tempo/interpol.py:260-378) on a sampled table.  cols: float64
+    device tensors (at most 16).  Returns dict(n, src, key, ts, ts_interp, val[c], valid[c],
+    interp[c]) with rows in (key, ts) order."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    if len(cols) > _lib.TMP_MAX_MASKS:
+        raise NotImplementedError(f"at most {_lib.TMP_MAX_MASKS} target columns per call")
+    for i, c in enumerate(cols):
+        _dev(c, torch.float64, f"cols[{i}]", n)
+        _dev(cols_valid[i], torch.uint8, f"cols_valid[{i}]", n)
+    k = len(cols)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = _lib.InterpolateArgs()
+    a.n, a.key, a.n_keys, a.ts, a.freq_us = n, _p(key), int(n_keys), _p(ts), int(freq_us)
+    a.method, a.n_cols = FILL_CODES[method], k
+    keep = [ptr_array([c.data_ptr() for c in cols]), ptr_array([0 if v is None else v.data_ptr() for v in cols_valid])]
+    a.cols, a.col_valid = keep
+    a.out_count = _p(count)
+    ws = _workspace(lib().tmp_interpolate_workspace_bytes(C.byref(a)), dev)
+    # first call sizes the result (capacity 0), the second one fills it
+    a.capacity = 0
+    rc = lib().tmp_interpolate(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+    if rc not in (0, _lib.TMP_ECAPACITY):
+        check(rc, "tmp_interpolate")
+    m = int(count.item())
+    cap = max(m, 1)
+    src = torch.empty(cap, dtype=torch.int32, device=dev)
+    okey = torch.empty(cap, dtype=torch.int32, device=dev)
+    ots = torch.empty(cap, dtype=torch.int64, device=dev)
+    tsi = torch.empty(cap, dtype=torch.uint8, device=dev)
+    val = torch.empty((max(k, 1), cap), dtype=torch.float64, device=dev)
+    valid = torch.empty((max(k, 1), cap), dtype=torch.uint8, device=dev)
+    interp = torch.empty((max(k, 1), cap), dtype=torch.uint8, device=dev)
+    if m:
+        a.capacity = cap
+        a.out_src, a.out_key, a.out_ts, a.out_ts_interp = _p(src), _p(okey), _p(ots), _p(tsi)
+        a.out_val, a.out_valid, a.out_interp = _p(val), _p(valid), _p(interp)
+        check(lib().tmp_interpolate(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_interpolate")
+    return dict(n=m, src=src[:m], key=okey[:m], ts=ots[:m], ts_interp=tsi[:m], val=[val[c, :m] for c in range(k)],
+                valid=[valid[c, :m] for c in range(k)], interp=[interp[c, :m] for c in range(k)])
+
+
 def hash_partition(key, n_parts):
     """Bucket rows by owner = hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts])."""
     n = key.numel()

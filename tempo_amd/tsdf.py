@@ -15,6 +15,7 @@ import torch
 from . import columns as col
 from . import ops
 from . import resample as rs
+from .interpol import Interpolation
 
 logger = logging.getLogger(__name__)
 
@@ -325,6 +326,24 @@ class TSDF:
         return _ResampledTSDF(enriched_df, ts_col=self.ts_col, partition_cols=self.partitionCols, freq=freq,
                               func=func)
 
+    def interpolate(self, freq, func, method, target_cols=None, ts_col=None, partition_cols=None,
+                    show_interpolated=False):
+        """Resample to `freq` with `func`, generate the missing timestamps and fill them by
+        `method` (zero / null / bfill / ffill / linear) -- python/tempo/tsdf.py:778-811."""
+        if ts_col is None:
+            ts_col = self.ts_col
+        if partition_cols is None:
+            partition_cols = self.partitionCols
+        if target_cols is None:
+            prohibited_cols = partition_cols + [ts_col]
+            target_cols = [c for c in self.df.columns
+                           if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+        interpolate_service = Interpolation(is_resampled=False)
+        tsdf_input = TSDF(self.df, ts_col=ts_col, partition_cols=partition_cols)
+        interpolated_df = interpolate_service.interpolate(tsdf_input, ts_col, partition_cols, target_cols, freq,
+                                                          func, method, show_interpolated)
+        return TSDF(interpolated_df, ts_col=ts_col, partition_cols=partition_cols)
+
     def calc_bars(tsdf, freq, func=None, metricCols=None, fill=None):
         """OHLC bars = floor / min / max / ceil per bucket joined on (key, ts)
         (python/tempo/tsdf.py:813-826)."""
@@ -345,3 +364,16 @@ class _ResampledTSDF(TSDF):  # python/tempo/tsdf.py:905-909
         super(_ResampledTSDF, self).__init__(df, ts_col, partition_cols, sequence_col)
         self.__freq = freq
         self.__func = func
+
+    def interpolate(self, method, target_cols=None, show_interpolated=False):
+        """Fill an already sampled table (python/tempo/tsdf.py:911-944)."""
+        if target_cols is None:
+            prohibited_cols = self.partitionCols + [self.ts_col]
+            target_cols = [c for c in self.df.columns
+                           if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+        interpolate_service = Interpolation(is_resampled=True)
+        tsdf_input = TSDF(self.df, ts_col=self.ts_col, partition_cols=self.partitionCols)
+        interpolated_df = interpolate_service.interpolate(
+            tsdf=tsdf_input, ts_col=self.ts_col, partition_cols=self.partitionCols, target_cols=target_cols,
+            freq=self.__freq, func=self.__func, method=method, show_interpolated=show_interpolated)
+        return TSDF(interpolated_df, ts_col=self.ts_col, partition_cols=self.partitionCols)

@@ -88,3 +88,12 @@ def grouped_stats(key, ts, n_keys, dur_us, cols, cols_valid):
                 max=[_t(np.ascontiguousarray(r["max"][c])) for c in range(k)],
                 sum=[_t(np.ascontiguousarray(r["sum"][c])) for c in range(k)],
                 stddev=[_t(r["stddev"][c]) for c in range(k)], is_i64=r["is_i64"])
+
+
+def interpolate(key, ts, n_keys, freq_us, method, cols, cols_valid):
+    r = oracle.interpolate(_np(key), _np(ts), freq_us, method, [_np(c) for c in cols], [_np(v) for v in cols_valid])
+    k = len(cols)
+    return dict(n=r["n"], src=_t(r["src"], torch.int32), key=_t(r["key"]), ts=_t(r["ts"]), ts_interp=_t(r["ts_interp"]),
+                val=[_t(np.ascontiguousarray(r["val"][c])) for c in range(k)],
+                valid=[_t(np.ascontiguousarray(r["valid"][c])) for c in range(k)],
+                interp=[_t(np.ascontiguousarray(r["interp"][c])) for c in range(k)])

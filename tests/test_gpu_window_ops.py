@@ -232,3 +232,64 @@ def test_grouped_stats_empty_and_single_series(orc, ops):
     assert r["n"] == 5 and r["count"][0].cpu().numpy().tolist() == [2] * 5
     assert r["mean"][0].cpu().numpy().tolist() == [0.5, 2.5, 4.5, 6.5, 8.5]
     np.testing.assert_allclose(r["stddev"][0].cpu().numpy(), np.full(5, np.sqrt(0.5)), rtol=1e-12)
+
+
+def _sampled_table(rng, n_keys, buckets, freq, p_keep, p_null, n_cols):
+    """A sampled table: per key a random subset of a regular grid, values with NULLs."""
+    keys, stamps = [], []
+    for k in range(n_keys):
+        keep = np.flatnonzero(rng.random(buckets) < p_keep)
+        keys.append(np.full(keep.size, k, np.int32))
+        stamps.append(1_577_836_800_000_000 + keep.astype(np.int64) * freq)
+    key, ts = np.concatenate(keys), np.concatenate(stamps)
+    o = rng.permutation(key.size)
+    key, ts = key[o], ts[o]
+    cols = [rng.normal(100, 5, key.size) for _ in range(n_cols)]
+    valid = [(rng.random(key.size) >= p_null).astype(np.uint8) for _ in range(n_cols)]
+    return key, ts, cols, valid
+
+
+@pytest.mark.parametrize("method", ["zero", "null", "bfill", "ffill", "linear"])
+@pytest.mark.parametrize("freq,p_keep,p_null", [(30_000_000, 0.4, 0.3), (1_000_000, 0.9, 0.05), (3_600_000_000, 0.1, 0.6)])
+def test_interpolate(orc, ops, method, freq, p_keep, p_null):
+    """Interpolation core against the oracle: rows, timestamps, flags and every filled value are
+    bit-exact (same fp64 operations in the same order, no contraction)."""
+    rng = np.random.default_rng(int(freq % 97) + len(method))
+    key, ts, cols, valid = _sampled_table(rng, 11, 700, freq, p_keep, p_null, 3)
+    valid[2] = None
+    r = ops.interpolate(_dev(key), _dev(ts), 11, freq, method, [_dev(c) for c in cols],
+                        [None if v is None else _dev(v) for v in valid])
+    e = orc.interpolate(key, ts, freq, method, cols, valid)
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["src"].cpu().numpy(), e["src"])
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["ts"].cpu().numpy(), e["ts"])
+    assert np.array_equal(r["ts_interp"].cpu().numpy(), e["ts_interp"])
+    for c in range(3):
+        ok = r["valid"][c].cpu().numpy()
+        assert np.array_equal(ok, e["valid"][c]), c
+        assert np.array_equal(r["interp"][c].cpu().numpy(), e["interp"][c]), c
+        got, want = r["val"][c].cpu().numpy(), e["val"][c]
+        assert np.array_equal(got[ok == 1].view(np.int64), want[ok == 1].view(np.int64)), c
+
+
+def test_interpolate_edges(orc, ops):
+    e = ops.interpolate(None, _dev(np.zeros(0, np.int64)), 1, 1_000_000, "linear", [], [])
+    assert e["n"] == 0
+    # one row per key: every key yields exactly its own row
+    key = np.arange(5, dtype=np.int32)
+    ts = np.full(5, 1_577_836_800_000_000, np.int64)
+    x = np.arange(5, dtype=np.float64)
+    r = ops.interpolate(_dev(key), _dev(ts), 5, 60_000_000, "linear", [_dev(x)], [None])
+    assert r["n"] == 5 and r["val"][0].cpu().numpy().tolist() == x.tolist()
+    assert not r["ts_interp"].cpu().numpy().any()
+    # no key column, pre-epoch timestamps (unix_timestamp floors), a wide gap
+    ts = np.array([-3_600_000_000, -1_800_000_000, 7_200_000_000], np.int64)
+    x = np.array([1.0, 0.0, 9.0])
+    v = np.array([1, 0, 1], np.uint8)
+    r = ops.interpolate(None, _dev(ts), 1, 600_000_000, "linear", [_dev(x)], [_dev(v)])
+    o = orc.interpolate(None, ts, 600_000_000, "linear", [x], [v])
+    assert r["n"] == o["n"] == 19
+    assert np.array_equal(r["val"][0].cpu().numpy().view(np.int64), o["val"][0].view(np.int64))
+    # rows closer than the frequency are rejected, as Spark's sequence() rejects them
+    with pytest.raises(ValueError, match="closer than freq_us"):
+        ops.interpolate(None, _dev(np.array([0, 10, 20], np.int64)), 1, 15, "zero", [], [])

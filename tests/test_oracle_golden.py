@@ -153,3 +153,32 @@ def test_grouped_stats_vector_via_bucket_stats(orc, golden):
     for b, erow in enumerate(fx["expected"]):
         assert r["start"][b] == ts_us(erow[1])
         assert abs(r["f64"][0][b] - erow[2]) < 0.00501
+
+
+@pytest.mark.parametrize("method", ["zero", "null", "bfill", "ffill", "linear"])
+def test_interpolate_vectors(orc, golden, method):
+    """interpol_tests.py:154-352 on the oracle itself: the sampled series (30 s means of
+    simple_data, computed by the oracle's resample) upsampled and filled."""
+    fx = golden["interpolate"]
+    T = _table(fx["columns"], fx["data"])
+    ts = np.array([ts_us(s) for s in T["event_ts"]])
+    cols, valid = [], []
+    for c in ("value_a", "value_b"):
+        v = np.array([np.nan if x is None else x for x in T[c]], np.float32).astype(np.float64)
+        valid.append((~np.isnan(v)).astype(np.uint8))
+        cols.append(np.nan_to_num(v))
+    key = np.zeros(len(ts), np.int32)
+    rs = orc.resample(key, ts, 30_000_000, "mean", cols, valid)
+    r = orc.interpolate(rs["key"], rs["start"], 30_000_000, method,
+                        [rs["f64"][0], rs["f64"][1]], [rs["valid"][0], rs["valid"][1]])
+    exp = fx["expected"][method]
+    assert r["n"] == len(exp)
+    for q, row in enumerate(exp):
+        assert r["ts"][q] == ts_us(row[2])
+        for c in range(2):
+            if row[3 + c] is None:
+                assert r["valid"][c][q] == 0, (q, c)
+            else:
+                assert r["valid"][c][q] == 1 and r["val"][c][q] == row[3 + c], (q, c)
+        assert bool(r["ts_interp"][q]) == row[5]
+        assert bool(r["interp"][0][q]) == row[6] and bool(r["interp"][1][q]) == row[7]

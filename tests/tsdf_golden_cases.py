@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -138,6 +139,58 @@ def case_grouped_stats(TSDF):
     assert one["count_trade_pr"].tolist() == [2, 2]
 
 
+def case_interpolate(TSDF):
+    """interpol_tests.py:154-595: every fill method on the simple series, the TSDF entry points,
+    the resample().interpolate() chain and the validation errors."""
+    fx = _golden()["interpolate"]
+    df = build_df(fx["columns"], fx["data"], float32=fx["float32_columns"])
+    t = TSDF(df, partition_cols=["partition_a", "partition_b"], ts_col="event_ts")
+    for method, rows in fx["expected"].items():
+        exp = build_df(fx["expected_columns"], rows)
+        got = t.interpolate(freq=fx["freq"], func=fx["func"], method=method, show_interpolated=True,
+                            target_cols=["value_a", "value_b"]).df
+        assert list(got.columns) == fx["expected_columns"], method
+        assert got["value_a"].dtype == np.float64 and got["is_ts_interpolated"].dtype == bool
+        assert got["event_ts"].tolist() == exp["event_ts"].tolist(), method   # rows come back in (key, ts) order
+        assert_frames_equal(got, exp)
+    # defaults: ts_col / partition_cols from the TSDF, every numeric column, flags hidden (:406-444)
+    lin = build_df(fx["expected_columns"], fx["expected"]["linear"])
+    got = t.interpolate(freq="30 seconds", func="mean", method="linear").df
+    assert list(got.columns) == fx["columns"]
+    assert_frames_equal(got, lin[fx["columns"]])
+    # another ts_col name, one target (:446-495)
+    t2 = TSDF(df.rename(columns={"event_ts": "other_ts_col"}), partition_cols=["partition_a", "partition_b"],
+              ts_col="other_ts_col")
+    got = t2.interpolate(ts_col="other_ts_col", show_interpolated=True, partition_cols=["partition_a", "partition_b"],
+                         target_cols=["value_a"], freq="30 seconds", func="mean", method="linear").df
+    exp = lin.rename(columns={"event_ts": "other_ts_col"})[
+        ["partition_a", "partition_b", "other_ts_col", "value_a", "is_ts_interpolated", "is_interpolated_value_a"]]
+    assert list(got.columns) == list(exp.columns)
+    assert_frames_equal(got, exp)
+    # constructor parameters of the result (:497-512)
+    r = t.interpolate(ts_col="event_ts", show_interpolated=True, partition_cols=["partition_b"],
+                      target_cols=["value_a"], freq="30 seconds", func="mean", method="linear")
+    assert r.ts_col == "event_ts" and r.partitionCols == ["partition_b"]
+    # resample(...).interpolate(...) (:514-595)
+    got = t.resample(freq="30 seconds", func="mean", fill=None).interpolate(
+        method="linear", target_cols=["value_a"], show_interpolated=True).df
+    assert_frames_equal(got, lin[["partition_a", "partition_b", "event_ts", "value_a", "is_ts_interpolated",
+                                  "is_interpolated_value_a"]])
+    got = t.resample(freq="30 seconds", func="mean", fill=None).interpolate(method="ffill").df
+    assert_frames_equal(got, build_df(fx["expected_columns"], fx["expected"]["ffill"])[fx["columns"]])
+    # validation (:78-152)
+    kw = dict(freq="30 seconds", func="mean", show_interpolated=True)
+    with pytest.raises(ValueError, match="fill options"):
+        t.interpolate(method="abcd", target_cols=["value_a", "value_b"], **kw)
+    with pytest.raises(ValueError, match="Target Column needs to be one of"):
+        t.interpolate(method="zero", target_cols=["partition_a", "value_b"], **kw)
+    with pytest.raises(ValueError):
+        t.interpolate(method="zero", partition_cols=["partition_c", "partition_b"],
+                      target_cols=["value_a", "value_b"], **kw)
+    with pytest.raises(ValueError):
+        t.interpolate(method="zero", ts_col="value_a", target_cols=["value_a", "value_b"], **kw)
+
+
 def case_resample(TSDF):
     fx = _golden()["resample"]
     df = build_df(fx["columns"], fx["data"], float32=fx["float32_columns"])
@@ -223,4 +276,4 @@ def case_errors(TSDF):
 
 
 ALL_CASES = [case_asof_basic, case_asof_skip_nulls, case_asof_sequence, case_asof_skew, case_range_stats,
-             case_grouped_stats, case_resample, case_resample_fill, case_ema, case_lookback, case_errors]
+             case_grouped_stats, case_interpolate, case_resample, case_resample_fill, case_ema, case_lookback, case_errors]
