@@ -206,23 +206,28 @@ struct SkewParams {
   double one_minus_fraction;
 };
 
-__device__ __forceinline__ void bracket_of(int64_t ts, const SkewParams &sp, double *part,
-                                           double *rem) {
-  double d = sp.ts_is_seconds ? (double)ts : (double)ts / 1000000.0;
-  int32_t q = spark_d2i(d / sp.v);
-  double p = sp.v_is_int ? (double)(int32_t)((uint32_t)(int32_t)sp.v * (uint32_t)q) : sp.v * (double)q;
-  *part = p;
-  *rem = (d - p) / sp.v;
+__device__ __forceinline__ double bracket_seconds(int64_t ts, const SkewParams &sp) {
+  return sp.ts_is_seconds ? (double)ts : (double)ts / 1000000.0;
 }
 
+// ts_partition of tsdf.py:178-180 for a row whose double timestamp is d.
+__device__ __forceinline__ double bracket_part(double d, const SkewParams &sp) {
+  int32_t q = spark_d2i(d / sp.v);
+  return sp.v_is_int ? (double)(int32_t)((uint32_t)(int32_t)sp.v * (uint32_t)q) : sp.v * (double)q;
+}
+
+// A right row is visible from the left row's bracket when it lies in that bracket, or in the
+// one before it with a remainder inside the carried-over tail (tsdf.py:181-188).  The
+// remainder -- one more division -- is only worked out in the second case.
 __device__ __forceinline__ bool bracket_visible(int64_t ts_right, double part_left,
                                                 const SkewParams &sp) {
-  double pr, rr;
-  bracket_of(ts_right, sp, &pr, &rr);
+  double d = bracket_seconds(ts_right, sp);
+  double pr = bracket_part(d, sp);
   if (pr == part_left) return true;
   double nxt = sp.v_is_int ? (double)(int32_t)((uint32_t)(int32_t)pr + (uint32_t)(int32_t)sp.v)
                            : pr + sp.v;
-  return nxt == part_left && rr >= sp.one_minus_fraction;
+  if (nxt != part_left) return false;
+  return (d - pr) / sp.v >= sp.one_minus_fraction;
 }
 
 // Number of right rows ordered at or before the left sort word `key` (low bits dropped).
@@ -337,8 +342,8 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     int64_t jr = pos - 1;
     uint32_t key_l = lay.key_of(wl);
     bool same = jr >= blo && lay.key_of(wr_row) == key_l;
-    double part_l = 0.0, rem_l;
-    if (sp.enabled) bracket_of(lay.prim_of(wl), sp, &part_l, &rem_l);
+    double part_l = 0.0;
+    if (sp.enabled) part_l = bracket_part(bracket_seconds(lay.prim_of(wl), sp), sp);
     uint32_t src_row = perm_l[i];
     uint32_t dst = sorted_output ? (uint32_t)i : src_row;
     if (sorted_output) {
@@ -391,7 +396,11 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
         int32_t j = lastnn[(size_t)m * n_right + jr];
         if (j >= 0) {
           wm = (staged && j >= blo) ? rw[j - blo] : comp_r[j];
-          if (lay.key_of(wm) == key_l && (!sp.enabled || bracket_visible(lay.prim_of(wm), part_l, sp))) jm = j;
+          if (j == jr) {  // the row rule already judged this row
+            if (jrow >= 0) jm = j;
+          } else if (lay.key_of(wm) == key_l && (!sp.enabled || bracket_visible(lay.prim_of(wm), part_l, sp))) {
+            jm = j;
+          }
         }
       }
       if (rec) rec[1 + m] = jm < 0 ? -1 : (jm == jrow && row_src >= 0 ? row_src : (int32_t)perm_r[jm]);
@@ -414,10 +423,15 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       }
     }
   }
-  if (__any(miss_row) && (threadIdx.x & 63) == 0) atomicOr(&out_missing[0], 1);
+  // one flag per rule; a wave raises it only while it still reads as clear (the flags are hot:
+  // unconditional atomics from every wave serialise on one address)
+  const bool lane0 = (threadIdx.x & 63) == 0;
+  if (__any(miss_row) && lane0 && __atomic_load_n(&out_missing[0], __ATOMIC_RELAXED) == 0)
+    atomicOr(&out_missing[0], 1);
   for (int m = 0; m < n_masks; ++m) {
     int any = __any((miss_mask >> m) & 1u);
-    if (any && (threadIdx.x & 63) == 0) atomicOr(&out_missing[1 + m], 1);
+    if (any && lane0 && __atomic_load_n(&out_missing[1 + m], __ATOMIC_RELAXED) == 0)
+      atomicOr(&out_missing[1 + m], 1);
   }
 }
 

@@ -230,19 +230,31 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
   }
 }
 
-// Exclusive scan of `total` uint32 counters in place, one block.
+// Exclusive scan of `total` uint32 counters in place, one block, 16 counters per thread and
+// round (four 16-byte loads; `counts` comes from the 256-byte aligned workspace).
 __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int total) {
+  constexpr int kPer = 16;
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < total; base += 4096) {
-    int i = base + tid * 4;
-    uint32_t v[4];
+  for (int base = 0; base < total; base += 1024 * kPer) {
+    int i = base + tid * kPer;
+    uint32_t v[kPer];
+    if (i + kPer <= total) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i + k < total) ? counts[i + k] : 0u;
-    uint32_t s = v[0] + v[1] + v[2] + v[3];
+      for (int k = 0; k < kPer; k += 4) {
+        uint4 q = *reinterpret_cast<const uint4 *>(counts + i + k);
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) v[k] = (i + k < total) ? counts[i + k] : 0u;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) s += v[k];
     uint32_t inc = s;
     for (int o = 1; o < 64; o <<= 1) {
       uint32_t t = __shfl_up(inc, o, 64);
@@ -257,10 +269,22 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
       tot += t;
     }
     uint32_t run = carry_s + wp + (inc - s);
+    if (i + kPer <= total) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (i + k < total) counts[i + k] = run;
-      run += v[k];
+      for (int k = 0; k < kPer; k += 4) {
+        uint4 q;
+        q.x = run; run += v[k];
+        q.y = run; run += v[k + 1];
+        q.z = run; run += v[k + 2];
+        q.w = run; run += v[k + 3];
+        *reinterpret_cast<uint4 *>(counts + i + k) = q;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        if (i + k < total) counts[i + k] = run;
+        run += v[k];
+      }
     }
     __syncthreads();
     if (tid == 0) carry_s += tot;
