@@ -312,12 +312,14 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
         if (ok[r]) {
           xv[r] = xs[rs + e];
           fin[r] = Ord<T>::finite(xv[r]);
-          if (fin[r]) atomicMin(&s.pivot_at, e);
-          else s.nonfinite = 1;
+          if (!fin[r]) s.nonfinite = 1;
         }
       }
       s.ck[e] = c;
       s.x[e] = xv[r];
+      // pivot = first finite value of the region: one LDS atomic per wave, not per slot
+      uint64_t bal = __ballot(fin[r]);
+      if (bal && lane == 0) atomicMin(&s.pivot_at, e + (int)__ffsll((long long)bal) - 1);
     }
   }
   __syncthreads();
