@@ -395,7 +395,14 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       if (same) {
         int32_t j = lastnn[(size_t)m * n_right + jr];
         if (j >= 0) {
-          wm = (staged && j >= blo) ? rw[j - blo] : comp_r[j];
+          // two typed loads, not one load through a pointer chosen at run time (that becomes
+          // a flat access, which waits on every outstanding global and LDS operation)
+          const bool in_lds = staged && j >= blo;
+          uint64_t w_lds = rw[in_lds ? (int)(j - blo) : 0];
+          asm volatile("" : "+v"(w_lds));  // keeps the compiler from merging the two loads again
+          uint64_t w_glb = 0;
+          if (!in_lds) w_glb = comp_r[j];
+          wm = in_lds ? w_lds : w_glb;
           if (j == jr) {  // the row rule already judged this row
             if (jrow >= 0) jm = j;
           } else if (lay.key_of(wm) == key_l && (!sp.enabled || bracket_visible(lay.prim_of(wm), part_l, sp))) {

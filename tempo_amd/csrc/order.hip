@@ -314,6 +314,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   __shared__ uint64_t skey[RS_TILE];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint64_t spay[PAY ? NPAY : 1][PAY ? RS_TILE : 1];
+  // A wave's lanes hand counts to each other through whist from one item to the next: those
+  // accesses are relaxed wavefront-scope atomics (plain ds_read / ds_write, kept in program
+  // order).  Not volatile: volatile LDS accesses are emitted as flat operations, which also
+  // wait on the global loads in flight.
   __shared__ uint32_t whist[RS_WAVES][RS_RADIX];
   __shared__ uint32_t dstart[RS_RADIX];
   __shared__ uint32_t goff[RS_RADIX];
@@ -321,7 +325,6 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   if (tid < RS_RADIX) goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
-  volatile uint32_t *wh = &whist[wave][0];
   // The pairs of the next tile are requested while the current one is ranked and reordered, so
   // that the block (the only one its CU has room for) keeps loads in flight through those phases.
   uint64_t k[RS_ITEMS], kn[RS_ITEMS];
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     int64_t tile_base = ((int64_t)blockIdx.x * tiles_per_block + t) * RS_TILE;
     if (tile_base >= n) break;
     int tile_n = (int)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
-    for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&whist[0][0])[i] = 0;
+    for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) whist[i / RS_RADIX][i % RS_RADIX] = 0;
     __syncthreads();
     uint64_t pay[PAY ? NPAY : 1][PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
@@ -374,15 +377,25 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
       bool valid = pos < tile_n;
       uint32_t d = (uint32_t)(k[it] >> shift) & mask;
-      uint64_t peers = __ballot(valid);
-      for (int b = 0; b < nbits; ++b) {
-        uint64_t bal = __ballot((d >> b) & 1u);
-        peers &= ((d >> b) & 1u) ? bal : ~bal;
+      // peers = lanes holding the same digit: per bit one ballot, then "keep the lanes that
+      // agree with me" as xnor with the bit spread over a word (bit set: keep the ballot,
+      // clear: keep its complement).  All RS_BITS bits, unrolled: bits above the pass's width
+      // are zero in every lane and keep everything.
+      const uint64_t vb = __ballot(valid);
+      uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
+#pragma unroll
+      for (int b = 0; b < RS_BITS; ++b) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
+        const uint64_t bal = __ballot(m != 0u);
+        plo &= ~((uint32_t)bal ^ m);
+        phi &= ~((uint32_t)(bal >> 32) ^ m);
       }
-      uint32_t prior = wh[d];
-      uint32_t cnt = (uint32_t)__popcll(peers);
+      const uint64_t peers = ((uint64_t)phi << 32) | plo;
+      uint32_t prior = __hip_atomic_load(&whist[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
       bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
-      if (leader) wh[d] = prior + cnt;
+      if (leader)
+        __hip_atomic_store(&whist[wave][d], prior + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       rank[it] = prior + (uint32_t)__popcll(peers & lt_mask);
     }
     __syncthreads();

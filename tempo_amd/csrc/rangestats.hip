@@ -402,14 +402,18 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       if (kInt) s.bi[0] = 0ull;
     }
   } else if (wave == 1 || wave == 2) {
-    volatile T *tab = wave == 1 ? &s.mn[0][0] : &s.mx[0][0];
+    // one wave per table; a wavefront-scope fence between levels keeps the level just written
+    // visible to the lanes that read it next (plain LDS accesses: volatile ones would be
+    // emitted as flat operations)
     for (int lv = 1; lv < RK_LEVELS; ++lv) {
       int span = 1 << lv;
       for (int b = lane; b + span <= RK_NSB; b += 64) {
-        T a0 = tab[(lv - 1) * RK_NSB + b], a1 = tab[(lv - 1) * RK_NSB + b + span / 2];
-        tab[lv * RK_NSB + b] = wave == 1 ? MinMax<T>::mn(a0, a1) : MinMax<T>::mx(a0, a1);
+        if (wave == 1) s.mn[lv][b] = MinMax<T>::mn(s.mn[lv - 1][b], s.mn[lv - 1][b + span / 2]);
+        else s.mx[lv][b] = MinMax<T>::mx(s.mx[lv - 1][b], s.mx[lv - 1][b + span / 2]);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   __syncthreads();
