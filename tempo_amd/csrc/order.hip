@@ -311,9 +311,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   constexpr int RS_WAVES = RS_THREADS / 64;
   constexpr int RS_RADIX = 1 << RS_BITS;
   static_assert(RS_RADIX <= RS_THREADS, "one thread per digit");
-  __shared__ uint64_t skey[RS_TILE];
-  __shared__ uint32_t sval[RS_TILE];
-  __shared__ uint64_t spay[PAY ? NPAY : 1][PAY ? RS_TILE : 1];
+  // One staging buffer, used in turn for the sort words, the row ids and each payload column:
+  // a tile is as large as the words alone allow, which makes the runs of equal digit -- the
+  // unit the scattered stores go out in -- that much longer.
+  __shared__ uint64_t sbuf[RS_TILE];
+  uint32_t *sbuf32 = reinterpret_cast<uint32_t *>(sbuf);
   // A wave's lanes hand counts to each other through whist from one item to the next: those
   // accesses are relaxed wavefront-scope atomics (plain ds_read / ds_write, kept in program
   // order).  Not volatile: volatile LDS accesses are emitted as flat operations, which also
@@ -325,18 +327,20 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   if (tid < RS_RADIX) goff[tid] = offsets[(size_t)tid * gridDim.x + blockIdx.x];
-  // The pairs of the next tile are requested while the current one is ranked and reordered, so
-  // that the block (the only one its CU has room for) keeps loads in flight through those phases.
-  uint64_t k[RS_ITEMS], kn[RS_ITEMS];
-  uint32_t v[RS_ITEMS], vn[RS_ITEMS];
-  {
+  // Payload passes read their payload through the row ids, a dependent chain of loads: there
+  // the pairs of the next tile are requested one tile ahead.  Plain passes use the registers
+  // for a larger tile instead.
+  constexpr bool PREFETCH = PAY;
+  uint64_t k[RS_ITEMS], kn[PREFETCH ? RS_ITEMS : 1];
+  uint32_t v[RS_ITEMS], vn[PREFETCH ? RS_ITEMS : 1];
+  if (PREFETCH) {
     int64_t base0 = (int64_t)blockIdx.x * tiles_per_block * RS_TILE;
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
       int64_t g = base0 + wave * (64 * RS_ITEMS) + it * 64 + lane;
       bool valid = g < n;
-      kn[it] = valid ? kin[g] : 0ull;
-      vn[it] = valid ? vin[g] : 0u;
+      kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
+      vn[PREFETCH ? it : 0] = valid ? vin[g] : 0u;
     }
   }
   for (int t = 0; t < tiles_per_block; ++t) {
@@ -348,19 +352,27 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     uint64_t pay[PAY ? NPAY : 1][PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
-#pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-      k[it] = kn[it];
-      v[it] = vn[it];
-    }
-    if (t + 1 < tiles_per_block) {
-      int64_t next_base = tile_base + RS_TILE;
+    if (PREFETCH) {
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
-        int64_t g = next_base + wave * (64 * RS_ITEMS) + it * 64 + lane;
-        bool valid = g < n;
-        kn[it] = valid ? kin[g] : 0ull;
-        vn[it] = valid ? vin[g] : 0u;
+        k[it] = kn[PREFETCH ? it : 0];
+        v[it] = vn[PREFETCH ? it : 0];
+      }
+      if (t + 1 < tiles_per_block) {
+        int64_t next_base = tile_base + RS_TILE;
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+          int64_t g = next_base + wave * (64 * RS_ITEMS) + it * 64 + lane;
+          bool valid = g < n;
+          kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
+          vn[PREFETCH ? it : 0] = valid ? vin[g] : 0u;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < RS_ITEMS; ++it) {
+        int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+        k[it] = pos < tile_n ? kin[tile_base + pos] : 0ull;
       }
     }
     if (PAY) {
@@ -423,34 +435,63 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       dstart[tid] = wp + cnt_inc - cnt_d;
     }
     __syncthreads();
+    // words: to their place in the tile's digit order, then out in runs
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
       int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
       if (pos < tile_n) {
         uint32_t d = (uint32_t)(k[it] >> shift) & mask;
-        uint32_t p = dstart[d] + whist[wave][d] + rank[it];
-        skey[p] = k[it];
-        sval[p] = v[it];
-        if (PAY) {
-#pragma unroll
-          for (int c = 0; c < NPAY; ++c) spay[c][PAY ? p : 0] = pay[c][PAY ? it : 0];
-        }
+        rank[it] += dstart[d] + whist[wave][d];  // from here on: the item's slot in the tile
+        sbuf[rank[it]] = k[it];
       }
+    }
+    __syncthreads();
+    uint32_t gpos[RS_ITEMS];  // global position of the tile slot tid + j * RS_THREADS
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+      int p = tid + j * RS_THREADS;
+      if (p < tile_n) {
+        uint64_t kk = sbuf[p];
+        uint32_t d = (uint32_t)(kk >> shift) & mask;
+        gpos[j] = goff[d] + ((uint32_t)p - dstart[d]);
+        kout[gpos[j]] = kk;
+      }
+    }
+    __syncthreads();
+    // row ids through the same buffer (read only now unless the payload needed them: fewer
+    // registers live while the tile is ranked)
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+      if (!PAY) v[it] = pos < tile_n ? vin[tile_base + pos] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+      if (pos < tile_n) sbuf32[rank[it]] = v[it];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
       int p = tid + j * RS_THREADS;
-      if (p < tile_n) {
-        uint64_t kk = skey[p];
-        uint32_t d = (uint32_t)(kk >> shift) & mask;
-        uint32_t g = goff[d] + ((uint32_t)p - dstart[d]);
-        kout[g] = kk;
-        vout[g] = sval[p];
-        if (PAY) {
+      if (p < tile_n) vout[gpos[j]] = sbuf32[p];
+    }
+    if (PAY) {
 #pragma unroll
-          for (int c = 0; c < NPAY; ++c)
-            if (c < pp.n) pp.out[c][g] = spay[c][PAY ? p : 0];
+      for (int c = 0; c < NPAY; ++c) {
+        if (c < pp.n) {  // uniform
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < RS_ITEMS; ++it) {
+            int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+            if (pos < tile_n) sbuf[rank[it]] = pay[c][PAY ? it : 0];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < RS_ITEMS; ++j) {
+            int p = tid + j * RS_THREADS;
+            if (p < tile_n) pp.out[c][gpos[j]] = sbuf[p];
+          }
         }
       }
     }
@@ -570,11 +611,11 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
         memset(&pp, 0, sizeof(pp));
         pp.n = n_pay - c0 < kMaxPay ? n_pay - c0 : kMaxPay;
         for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
-        radix_one_pass<1024, 4, 1>(b, n, cur, lo, nbits, st, pp);
+        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp);
       }
       if (carried) *carried = true;
     } else {
-      radix_one_pass<1024, 8, 0>(b, n, cur, lo, nbits, st, none);
+      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none);
     }
     lo += nbits;
     cur ^= 1;
