@@ -1,0 +1,183 @@
+"""Arrow edge of the hot path: pyarrow Tables in, pyarrow Tables out, no pandas in between.
+
+What a Spark-side caller (`mapInArrow` / `toArrow` per key-hash partition, or any Arrow
+producer) hands over and takes back for the two headline operators.  Columns go to HBM from
+the Arrow buffers themselves: partition keys are dictionary-encoded by Arrow (one dictionary
+shared by both sides of a join), `timestamp[*]` columns become int64 microseconds, numeric
+columns become float64 / int64 with the Arrow validity bitmap as the NULL mask.
+
+  asof_join(left, right, ...)   TSDF.asofJoin (python/tempo/tsdf.py:463-560) through the fused
+                                device join: the joined table in (key, ts) order
+  range_stats(table, ...)       TSDF.withRangeStats (python/tempo/tsdf.py:673-721)
+"""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import torch
+
+from . import columns as col
+from . import ops
+
+
+def _combined(arr):
+    if isinstance(arr, pa.ChunkedArray):
+        return arr.combine_chunks() if arr.num_chunks != 1 else arr.chunk(0)
+    return arr
+
+
+def encode_keys(tables, cols):
+    """Dictionary-encode the partition columns of several tables with one shared dictionary.
+    Returns ([int32 numpy codes per table], n_keys, decode) where decode(codes) -> list of
+    Arrow arrays, one per partition column.  NULL keys form their own group (as partitionBy)."""
+    if not cols:
+        return [None for _ in tables], 1, (lambda codes: [])
+    lens = [t.num_rows for t in tables]
+    combined, dicts = None, []
+    for c in cols:
+        whole = pa.concat_arrays([_combined(t[c]) for t in tables])
+        enc = pc.dictionary_encode(whole, null_encoding="encode")
+        codes = enc.indices.to_numpy(zero_copy_only=False).astype(np.int64)
+        dicts.append(enc.dictionary)
+        combined = codes if combined is None else combined * max(len(enc.dictionary), 1) + codes
+    radix = [max(len(d), 1) for d in dicts]
+    if len(cols) > 1:
+        uniq, dense = np.unique(combined, return_inverse=True)
+    else:
+        uniq, dense = np.arange(radix[0], dtype=np.int64), combined
+    n_keys = int(len(uniq)) if len(uniq) else 1
+    if n_keys >= 2 ** 31:
+        raise NotImplementedError("more than 2^31 distinct partition keys")
+
+    def decode(codes):
+        flat = uniq[np.asarray(codes, dtype=np.int64)]
+        out = []
+        for j in reversed(range(len(cols))):
+            out.append(dicts[j].take(pa.array(flat % radix[j], type=pa.int64())))
+            flat = flat // radix[j]
+        return out[::-1]
+
+    parts, at = [], 0
+    for n in lens:
+        parts.append(dense[at:at + n].astype(np.int32))
+        at += n
+    return parts, n_keys, decode
+
+
+def timestamps_us(arr):
+    """(int64 numpy microseconds, Arrow type) of a timestamp column; NULLs are rejected."""
+    arr = _combined(arr)
+    if not pa.types.is_timestamp(arr.type):
+        raise TypeError(f"time index column must be an Arrow timestamp, got {arr.type}")
+    if arr.null_count:
+        raise ValueError("NULL timestamps are not supported in the time index column")
+    raw = arr.cast(pa.int64()).to_numpy(zero_copy_only=False)
+    unit = arr.type.unit
+    if unit == "ns":
+        raw = np.floor_divide(raw, 1000)  # Spark keeps microseconds; floor also before the epoch
+    elif unit != "us":
+        raw = raw * {"s": 1_000_000, "ms": 1_000}[unit]
+    return raw, arr.type
+
+
+def payload_to_device(arr):
+    """(8-byte device tensor, uint8 validity tensor or None, decode) for a payload column of the
+    fused join: integers, floats, timestamps and dictionary-encodable columns (strings)."""
+    arr = _combined(arr)
+    valid = None
+    if arr.null_count:
+        valid = col.to_dev(pc.is_valid(arr).to_numpy(zero_copy_only=False).astype(np.uint8))
+    t = arr.type
+    if pa.types.is_floating(t):
+        vals = pc.fill_null(arr.cast(pa.float64()), 0.0).to_numpy(zero_copy_only=False)
+        dec = lambda v, ok: pa.array(v, type=pa.float64(), mask=~ok).cast(t)
+    elif pa.types.is_integer(t):
+        vals = pc.fill_null(arr.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
+    elif pa.types.is_timestamp(t):
+        vals = pc.fill_null(arr.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
+    else:
+        enc = pc.dictionary_encode(arr)
+        vals = pc.fill_null(enc.indices.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        dictionary = enc.dictionary
+        dec = lambda v, ok: dictionary.take(pa.array(v, type=pa.int64(), mask=~ok))
+    return col.to_dev(np.ascontiguousarray(vals)), valid, dec
+
+
+def _stamps(us, typ):
+    return pa.array(us, type=pa.int64()).cast(pa.timestamp("us", tz=typ.tz)).cast(typ)
+
+
+def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="right", skip_nulls=True,
+              ts_partition_val=None, fraction=0.5):
+    """AS-OF join of two Arrow tables.  Returns the joined table ordered by (partition, ts):
+    partition columns, the left columns, then `<right_prefix>_<name>` for every right column."""
+    partition_cols = list(partition_cols)
+    (key_l, key_r), n_keys, decode_keys = encode_keys([left, right], partition_cols)
+    ts_l, ts_type = timestamps_us(left[ts_col])
+    ts_r, ts_type_r = timestamps_us(right[ts_col])
+    if ts_type != ts_type_r:
+        raise ValueError("left and right dataframe timestamp index columns should have same type")
+    left_cols = [c for c in left.column_names if c not in partition_cols and c != ts_col]
+    right_cols = [c for c in right.column_names if c not in partition_cols]
+    lenc = [payload_to_device(left[c]) for c in left_cols]
+    renc = [payload_to_device(right[c]) for c in right_cols]
+    j = ops.asof_join_table(col.to_dev(key_l), col.to_dev(ts_l), col.to_dev(key_r), col.to_dev(ts_r), n_keys,
+                            [t for t, _, _ in lenc], [t for t, _, _ in renc], [v for _, v, _ in renc],
+                            skip_nulls=skip_nulls, ts_partition_val=ts_partition_val, fraction=fraction)
+    names, arrays = [], []
+    if partition_cols:
+        for c, a in zip(partition_cols, decode_keys(j["key"].cpu().numpy())):
+            names.append(c)
+            arrays.append(a)
+    names.append(ts_col)
+    arrays.append(_stamps(j["ts"].cpu().numpy(), ts_type))
+    perm = j["perm"]
+    for i, c in enumerate(left_cols):
+        values, valid, dec = lenc[i]
+        if valid is None:
+            ok = np.ones(left.num_rows, bool)
+        else:  # the NULL mask of a left column follows its rows through the permutation
+            ok = ops.gather(valid, perm, want_valid=False)[0].cpu().numpy().astype(bool)
+        names.append(c)
+        arrays.append(dec(j["left"][i].cpu().numpy(), ok))
+    for i, c in enumerate(right_cols):
+        vals, ok = j["right"][i]
+        names.append(f"{right_prefix}_{c}" if right_prefix != "" else c)
+        arrays.append(renc[i][2](vals.cpu().numpy(), ok.cpu().numpy().astype(bool)))
+    return pa.table(arrays, names=names)
+
+
+def range_stats(table, ts_col="event_ts", partition_cols=(), cols=(), range_back_secs=1000):
+    """withRangeStats on an Arrow table: the input rows in (partition, ts) order plus
+    mean_/count_/min_/max_/sum_/stddev_/zscore_<col> for every column in `cols`."""
+    partition_cols = list(partition_cols)
+    (key,), n_keys, _ = encode_keys([table], partition_cols)
+    ts, _ = timestamps_us(table[ts_col])
+    key_d, ts_d = col.to_dev(key), col.to_dev(ts)
+    out, perm = None, None
+    extra = {}
+    for c in cols:
+        arr = _combined(table[c])
+        if not (pa.types.is_floating(arr.type) or pa.types.is_integer(arr.type)):
+            raise TypeError(f"column {c} of type {arr.type} is not numeric")
+        x, valid, _ = payload_to_device(arr)
+        r = ops.range_stats(key_d, ts_d, x, valid, n_keys, range_back_secs)
+        flags = r["valid"].cpu().numpy()
+        ok, sd_ok, z_ok = (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0
+        perm = r["perm"].cpu().numpy() if perm is None else perm
+        as_in = pa.float64() if pa.types.is_floating(arr.type) else pa.int64()
+        extra["mean_" + c] = pa.array(r["mean"].cpu().numpy(), mask=~ok)
+        extra["count_" + c] = pa.array(r["count"].cpu().numpy())
+        extra["min_" + c] = pa.array(r["min"].cpu().numpy(), type=as_in, mask=~ok).cast(arr.type)
+        extra["max_" + c] = pa.array(r["max"].cpu().numpy(), type=as_in, mask=~ok).cast(arr.type)
+        extra["sum_" + c] = pa.array(r["sum"].cpu().numpy(), type=as_in, mask=~ok)
+        extra["stddev_" + c] = pa.array(r["stddev"].cpu().numpy(), mask=~sd_ok)
+        extra["zscore_" + c] = pa.array(r["zscore"].cpu().numpy(), mask=~z_ok)
+    if perm is None:
+        perm = ops.sort_order(key_d, ts_d, n_keys, floor_seconds=True).cpu().numpy() if table.num_rows else np.arange(0)
+    out = table.take(pa.array(perm.astype(np.int64)))
+    zs = [k for k in extra if k.startswith("zscore_")]
+    for k in [k for k in extra if not k.startswith("zscore_")] + zs:  # zscore columns last (tsdf.py:718-719)
+        out = out.append_column(k, extra[k])
+    return out

@@ -34,7 +34,10 @@ def to_pandas(df):
 def to_dev(a):
     if a is None:
         return None
-    return torch.from_numpy(np.ascontiguousarray(a)).to(device())
+    a = np.ascontiguousarray(a)
+    if not a.flags.writeable:  # Arrow buffers are read-only; torch wants a writable source
+        a = a.copy()
+    return torch.from_numpy(a).to(device())
 
 
 def spark_dtype(series):

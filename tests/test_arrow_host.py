@@ -1,0 +1,36 @@
+"""Arrow edge, host side only (no device): key dictionaries, timestamp units, payload encoding."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from tempo_amd import arrow_io
+
+
+def test_encode_keys_shared_dictionary_and_decode():
+    a = pa.table({"sym": ["B", "A", None, "B"], "ven": ["x", "x", "y", "y"]})
+    b = pa.table({"sym": ["A", "C"], "ven": ["x", "x"]})
+    (ka, kb), n, decode = arrow_io.encode_keys([a, b], ["sym", "ven"])
+    assert ka.dtype == np.int32 and n == 5            # (B,x) (A,x) (None,y) (B,y) (C,x)
+    assert ka[1] == kb[0] and len({*ka.tolist(), *kb.tolist()}) == 5
+    cols = decode(np.concatenate([ka, kb]))
+    assert cols[0].to_pylist() == ["B", "A", None, "B", "A", "C"]
+    assert cols[1].to_pylist() == ["x", "x", "y", "y", "x", "x"]
+    (k1,), n1, _ = arrow_io.encode_keys([a], [])
+    assert k1 is None and n1 == 1
+
+
+@pytest.mark.parametrize("unit,scale", [("s", 1_000_000), ("ms", 1000), ("us", 1), ("ns", None)])
+def test_timestamps_to_microseconds(unit, scale):
+    raw = [1_596_240_000, 1_596_240_001]
+    if unit == "ns":
+        arr = pa.array([r * 10**9 + 1999 for r in raw], type=pa.timestamp("ns"))
+        want = [r * 10**6 + 1 for r in raw]            # floor to microseconds
+    else:
+        arr = pa.array(raw, type=pa.timestamp(unit, tz="UTC" if unit == "ms" else None))
+        want = [r * scale for r in raw]
+    us, typ = arrow_io.timestamps_us(pa.chunked_array([arr.slice(0, 1), arr.slice(1)]))
+    assert us.dtype == np.int64 and us.tolist() == want and typ == arr.type
+    with pytest.raises(ValueError, match="NULL timestamps"):
+        arrow_io.timestamps_us(pa.array([None, 1], type=pa.timestamp("us")))
+    with pytest.raises(TypeError):
+        arrow_io.timestamps_us(pa.array([1, 2]))
