@@ -38,6 +38,7 @@ extern "C" {
 #define TMP_EHIP (-3)         /* HIP runtime error */
 #define TMP_EUNSUPPORTED (-4) /* valid request outside what this build supports */
 #define TMP_ECAPACITY (-5)    /* the result has more rows than the caller made room for */
+#define TMP_EWIDE (-6)        /* tmp_range_stats: needs the wide workspace (see there) */
 
 int tmp_abi_version(void);
 /* Thread-local text of the last error on the calling thread ("" if none). */
@@ -190,7 +191,13 @@ typedef struct {
   uint8_t *out_valid;
 } tmp_range_stats_args;
 
+/* Two workspace sizes.  The plain one serves every table whose frames stay inside a block's
+ * on-chip region (about 1280 rows back from a row, 256 same-second rows after it).  If some
+ * frame is longer, a call with the plain workspace returns TMP_EWIDE (nothing usable has been
+ * written); a call with the wide workspace completes those rows through per-chunk prefix
+ * arrays in global memory, at a cost that does not grow with the frame length. */
 size_t tmp_range_stats_workspace_bytes(const tmp_range_stats_args *a);
+size_t tmp_range_stats_wide_workspace_bytes(const tmp_range_stats_args *a);
 int tmp_range_stats(const tmp_range_stats_args *a, void *workspace, size_t workspace_bytes,
                     void *stream);
 

@@ -15,6 +15,7 @@ TMP_MAX_TAPS = 1024
 TMP_MAX_FEATURES = 64
 TMP_MAX_COLS = 64
 TMP_ECAPACITY = -5
+TMP_EWIDE = -6
 FUNC_CODES = {"floor": 0, "min": 1, "max": 2, "mean": 3, "ceil": 4}
 
 _vp = C.c_void_p
@@ -106,6 +107,7 @@ SYMBOLS = {
     "tmp_asof_join": _OP(AsofArgs),
     "tmp_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]),
     "tmp_range_stats_workspace_bytes": _WS(RangeStatsArgs),
+    "tmp_range_stats_wide_workspace_bytes": _WS(RangeStatsArgs),
     "tmp_range_stats": _OP(RangeStatsArgs),
     "tmp_ema_workspace_bytes": _WS(EmaArgs),
     "tmp_ema": _OP(EmaArgs),

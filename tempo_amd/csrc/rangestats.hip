@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "rangestats_common.h"
 
 namespace tmp {
 
@@ -25,115 +26,6 @@ constexpr int RK_FWD = 256;  // rows staged after the tile
 constexpr int RK_SB = 8;                 // slots per sub-block (half a DPP row)
 constexpr int RK_NSB = RK_CAP / RK_SB;  // 320
 constexpr int RK_LEVELS = 8;            // spans up to 128 sub-blocks; longer runs use three spans
-
-template <typename T>
-struct Ord;
-template <>
-struct Ord<double> {  // Spark ordering: NaN greatest, -0.0 == 0.0
-  static __device__ __forceinline__ bool lt(double a, double b) {
-    if (a != a) return false;
-    if (b != b) return true;
-    return a < b;
-  }
-  static __device__ __forceinline__ double min_id() { return __builtin_nan(""); }
-  static __device__ __forceinline__ double max_id() { return -__builtin_inf(); }
-  static __device__ __forceinline__ bool finite(double v) { return __builtin_isfinite(v); }
-};
-template <>
-struct Ord<int64_t> {
-  static __device__ __forceinline__ bool lt(int64_t a, int64_t b) { return a < b; }
-  static __device__ __forceinline__ int64_t min_id() { return INT64_MAX; }
-  static __device__ __forceinline__ int64_t max_id() { return INT64_MIN; }
-  static __device__ __forceinline__ bool finite(int64_t) { return true; }
-};
-
-template <typename T>
-struct RsOut {
-  int32_t *perm;
-  double *mean;
-  int64_t *count;
-  T *mn;
-  T *mx;
-  T *sum;
-  double *stddev;
-  double *zscore;
-  uint8_t *valid;
-};
-
-template <typename T>
-__device__ __forceinline__ void rs_store(const RsOut<T> &o, int64_t i, int64_t n, double mean,
-                                         T mn, T mx, T sum, bool sd_ok, double sd, bool x_ok,
-                                         double xd) {
-  o.count[i] = n;
-  bool ok = n > 0;
-  o.mean[i] = ok ? mean : 0.0;
-  o.mn[i] = ok ? mn : (T)0;
-  o.mx[i] = ok ? mx : (T)0;
-  o.sum[i] = ok ? sum : (T)0;
-  o.stddev[i] = sd_ok ? sd : 0.0;
-  bool z_ok = x_ok && sd_ok && sd != 0.0;  // Spark Divide: NULL on a zero divisor
-  o.zscore[i] = z_ok ? (xd - mean) / sd : 0.0;
-  o.valid[i] = (uint8_t)((ok ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
-}
-
-// Exact row-sequential evaluation of one frame: the recurrence Spark's aggregates run
-// (Sum / Average: running add; CentralMomentAgg: n, avg, m2 update per value).
-template <typename T>
-__device__ void rs_row_serial(const uint64_t *comp, const T *xs, int64_t lo, int64_t hi, int64_t i,
-                              const RsOut<T> &o) {
-  int64_t n = 0;
-  T mn = Ord<T>::min_id(), mx = Ord<T>::max_id();
-  double dsum = 0.0, avg = 0.0, m2 = 0.0, nn = 0.0;
-  uint64_t isum = 0;
-  for (int64_t j = lo; j <= hi; ++j) {
-    if (!(comp[j] & 1ull)) continue;
-    T v = xs[j];
-    if (n == 0) { mn = v; mx = v; }
-    else {
-      if (Ord<T>::lt(v, mn)) mn = v;
-      if (Ord<T>::lt(mx, v)) mx = v;
-    }
-    ++n;
-    nn += 1.0;
-    double vd = (double)v;
-    dsum += vd;
-    isum += (uint64_t)v;
-    double delta = vd - avg;
-    double delta_n = delta / nn;
-    avg += delta_n;
-    m2 += delta * (delta - delta_n);
-  }
-  T sum;
-  if constexpr (sizeof(T) == 8 && ((T)0.5 == (T)0)) sum = (T)isum; else sum = (T)dsum;
-  bool x_ok = (comp[i] & 1ull) != 0;
-  rs_store<T>(o, i, n, n ? dsum / (double)n : 0.0, mn, mx, sum, n > 1,
-              n > 1 ? sqrt(m2 / (nn - 1.0)) : 0.0, x_ok, (double)xs[i]);
-}
-
-__device__ __forceinline__ int64_t lower_bound_k(const uint64_t *comp, int64_t lo, int64_t hi,
-                                                 uint64_t key, int low) {
-  while (lo < hi) {
-    int64_t mid = lo + ((hi - lo) >> 1);
-    if ((comp[mid] >> low) < key) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-__device__ __forceinline__ int64_t upper_bound_k(const uint64_t *comp, int64_t lo, int64_t hi,
-                                                 uint64_t key, int low) {
-  while (lo < hi) {
-    int64_t mid = lo + ((hi - lo) >> 1);
-    if ((comp[mid] >> low) <= key) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
-// First sort word (low bits dropped) inside the frame of a row whose word is k.
-__device__ __forceinline__ uint64_t frame_start_key(uint64_t k, uint64_t prim_mask, uint64_t w) {
-  uint64_t rel = k & prim_mask;
-  return (k - rel) + (rel > w ? rel - w : 0);
-}
 
 // ---- 8-lane inclusive scans inside a DPP row (row_shr 1, 2, 4): lanes 7 and 15 of every row
 //      end up with the totals of their 8-lane halves.
@@ -226,23 +118,6 @@ struct MinMax<int64_t> {
 
 constexpr uint32_t RK_SAT = 0x7fffffffu;  // saturated relative sort word
 
-// 1/a and sqrt(a) from the hardware approximations plus one Newton step each: a few ulps, far
-// inside the 1e-9 the statistics are held to, at a fraction of the IEEE expansions' cost.
-__device__ __forceinline__ double fast_rcp(double a) {
-  double r = __builtin_amdgcn_rcp(a);
-  return __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
-}
-__device__ __forceinline__ double fast_sqrt(double a) {
-  if (!(a > 0.0)) return 0.0;
-  double y = __builtin_amdgcn_rsq(a);
-  double g = a * y, h = 0.5 * y;
-  double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  double d = __builtin_fma(-g, g, a);  // residual a - g^2
-  return __builtin_fma(d, h, g);
-}
-
 // One staged slot of a double metric into the frame's running sums; NULL slots hold NaN.
 __device__ __forceinline__ void slot_add_f64(double v, double pivot, double &sd, double &sq, uint32_t &dc,
                                              double &mn, double &mx) {
@@ -274,7 +149,8 @@ template <typename T>
 __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t *comp,
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
-                                                                 uint64_t w, RsOut<T> o) {
+                                                                 uint64_t w, RsOut<T> o,
+                                                                 int32_t *deferred) {
   constexpr bool kInt = ((T)0.5 == (T)0);
   __shared__ RsShared<T> s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,12 +382,17 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
     }
     slow = (dc >> 16) != 0;  // a non-finite value inside the frame
   }
+  // A frame that leaves the staged region (or a region too wide for 32-bit relative words) is
+  // not evaluated here: the row is marked and the wide path completes it.
+  const bool defer = open_left || open_right || krel >= RK_SAT;
+  if (__any(defer) && lane == 0 && __atomic_load_n(deferred, __ATOMIC_RELAXED) == 0) atomicOr(deferred, 1);
+  if (defer) {
+    o.valid[i] = kDeferred;
+    return;
+  }
   if (slow) {
-    // exact sequential evaluation from global memory (Spark's own recurrence)
-    int64_t glo = rs + a, ghi = rs + b;
-    if (open_left || krel >= RK_SAT) glo = lower_bound_k(comp, 0, i, kstart, low);
-    if (open_right || krel >= RK_SAT) ghi = upper_bound_k(comp, i, n, k, low) - 1;
-    rs_row_serial<T>(comp, xs, glo, ghi, i, o);
+    // a non-finite value inside the frame: exact sequential evaluation (Spark's own recurrence)
+    rs_row_serial<T>(comp, xs, rs + a, rs + b, i, o);
     return;
   }
   const int64_t cnt = dc & 0xffffu;
@@ -560,15 +441,19 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
 struct RsPlan {
   OrderBuffers ob;
   uint64_t *xs;
+  int32_t *deferred;
+  RsWidePlan wide;
 };
 
-static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p) {
+static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p, bool with_wide) {
   order_plan(a->n, ws, &p->ob);
   p->xs = ws.take<uint64_t>((size_t)(a->n > 0 ? a->n : 1));
+  p->deferred = ws.take<int32_t>(1);
+  if (with_wide) rs_wide_plan(a->n, a->x_is_i64 != 0, ws, &p->wide);
 }
 
 template <typename T>
-static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
+static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipStream_t st) {
   OrderSpec s;
   memset(&s, 0, sizeof(s));
   s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts;
@@ -593,10 +478,21 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, hipStream_t st) {
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
   int grid = (int)((a->n + RK_ROWS - 1) / RK_ROWS);
+  TMP_CHECK_HIP(hipMemsetAsync(p.deferred, 0, sizeof(int32_t), st));
   TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm,
-                     xs, a->n, lay, (uint64_t)a->range_back_secs, o);
+                     xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred);
   TMP_CHECK_HIP(hipGetLastError());
-  return TMP_OK;
+  // one small blocking read: did any frame leave its block's region?
+  int32_t deferred = 0;
+  TMP_CHECK_HIP(hipMemcpyAsync(&deferred, p.deferred, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  TMP_CHECK_HIP(hipStreamSynchronize(st));
+  if (!deferred) return TMP_OK;
+  if (!have_wide) {
+    set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
+              "tmp_range_stats_wide_workspace_bytes() bytes");
+    return TMP_EWIDE;
+  }
+  return rs_wide_run<T>(res.comp, xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.wide, st);
 }
 
 }  // namespace tmp
@@ -607,7 +503,15 @@ extern "C" size_t tmp_range_stats_workspace_bytes(const tmp_range_stats_args *a)
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RsPlan p;
-  rs_plan(a, ws, &p);
+  rs_plan(a, ws, &p, false);
+  return ws.off;
+}
+
+extern "C" size_t tmp_range_stats_wide_workspace_bytes(const tmp_range_stats_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  RsPlan p;
+  rs_plan(a, ws, &p, true);
   return ws.off;
 }
 
@@ -621,10 +525,13 @@ extern "C" int tmp_range_stats(const tmp_range_stats_args *a, void *workspace,
   TMP_REQUIRE(a->ts && a->x && a->out_perm && a->out_mean && a->out_count && a->out_min && a->out_max &&
                   a->out_sum && a->out_stddev && a->out_zscore && a->out_valid,
               TMP_EINVAL, "tmp_range_stats: null pointer");
+  // a workspace large enough for the wide path enables it; the plain size serves every table
+  // whose frames stay inside the on-chip region
+  const bool have_wide = workspace_bytes >= tmp_range_stats_wide_workspace_bytes(a);
   Workspace ws(workspace, workspace_bytes);
   RsPlan p;
-  rs_plan(a, ws, &p);
+  rs_plan(a, ws, &p, have_wide);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_range_stats: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  return a->x_is_i64 ? rs_run<int64_t>(a, p, st) : rs_run<double>(a, p, st);
+  return a->x_is_i64 ? rs_run<int64_t>(a, p, have_wide, st) : rs_run<double>(a, p, have_wide, st);
 }

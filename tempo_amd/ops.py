@@ -227,7 +227,13 @@ def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=Fals
                        _p(out["count"]), _p(out["min"]), _p(out["max"]), _p(out["sum"]),
                        _p(out["stddev"]), _p(out["zscore"]), _p(out["valid"]))
     ws = _workspace(lib().tmp_range_stats_workspace_bytes(C.byref(a)), dev)
-    check(lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_range_stats")
+    rc = lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+    if rc == _lib.TMP_EWIDE:
+        # some frame is longer than a block's on-chip region: run again with room for the wide path
+        del ws
+        ws = _workspace(lib().tmp_range_stats_wide_workspace_bytes(C.byref(a)), dev)
+        rc = lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, "tmp_range_stats")
     return out
 
 

@@ -141,3 +141,84 @@ def test_range_stats_time_ordered_feed(orc, ops):
     key, ts, x, xv = _ticks(rng, 80_000, 12, 1.0, 0.01, sort=True)  # sort=True keeps arrival order
     assert (np.diff(ts) >= 0).all() and (np.diff(key) < 0).any()
     _compare(orc, ops, key, ts, x, xv, 12, 600)
+
+
+@pytest.mark.parametrize("kind", ["f64", "i64", "specials"])
+def test_range_stats_wide_frames_vs_oracle(orc, ops, kind):
+    """Frames of a few thousand rows (far beyond a block's LDS region), several keys, random row
+    order, NULLs: completed by the chunk-prefix path, same bar as the region kernel."""
+    rng = np.random.default_rng(77)
+    n, nk = 60_000, 3
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + rng.integers(0, 600_000_000, n)          # 10 minutes: 33 rows per key and second
+    xv = (rng.random(n) >= 0.02).astype(np.uint8)
+    if kind == "i64":
+        x = rng.integers(-10**15, 10**15, n)
+    else:
+        x = 1000 + rng.normal(0, 1, n).cumsum() * 0.05
+        if kind == "specials":
+            x[rng.integers(0, n, 12)] = np.nan
+            x[rng.integers(0, n, 6)] = np.inf
+            x[rng.integers(0, n, 6)] = -np.inf
+    _compare(orc, ops, key, ts, x, xv, nk, 120)          # ~4000-row frames
+
+
+def _numpy_reference(sec, x, W):
+    """Exact-enough statistics of RANGE BETWEEN W PRECEDING AND CURRENT ROW on one ordered
+    series without NULLs: extended-precision prefix sums of centred data, sparse tables."""
+    n = len(x)
+    A = np.searchsorted(sec, sec - W, side="left")
+    B = np.searchsorted(sec, sec, side="right") - 1
+    c = x.astype(np.longdouble) - np.longdouble(x.mean())
+    P = np.concatenate([[0], np.cumsum(c)])
+    Q = np.concatenate([[0], np.cumsum(c * c)])
+    cnt = (B - A + 1).astype(np.int64)
+    S, SS = P[B + 1] - P[A], Q[B + 1] - Q[A]
+    mean = (S / cnt + np.longdouble(x.mean())).astype(np.float64)
+    var = (SS - S * S / cnt) / np.maximum(cnt - 1, 1)
+    sd = np.sqrt(np.maximum(var, 0)).astype(np.float64)
+    lv = np.floor(np.log2(cnt)).astype(np.int64)
+    tmin, tmax = [x.copy()], [x.copy()]
+    for l in range(1, int(lv.max()) + 1):
+        h = 1 << (l - 1)
+        tmin.append(np.minimum(tmin[-1][:n - 2 * h + 1], tmin[-1][h:n - h + 1]))
+        tmax.append(np.maximum(tmax[-1][:n - 2 * h + 1], tmax[-1][h:n - h + 1]))
+    mn, mx = np.empty(n), np.empty(n)
+    for l in range(int(lv.max()) + 1):
+        m = lv == l
+        mn[m] = np.minimum(tmin[l][A[m]], tmin[l][B[m] + 1 - (1 << l)])
+        mx[m] = np.maximum(tmax[l][A[m]], tmax[l][B[m] + 1 - (1 << l)])
+    return cnt, mean, sd, mn, mx
+
+
+@pytest.mark.parametrize("trend", [0.0, 0.01])
+def test_range_stats_frames_across_superblocks(ops, trend):
+    """Frames of ~100 000 rows span several 65 536-row superblocks: pieces with different pivots
+    are merged pairwise.  Checked against an extended-precision numpy evaluation."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    ts = BASE + np.sort(rng.integers(0, 3_000_000_000, n))   # 3000 s, 100 rows per second
+    x = 500 + rng.normal(0, 1, n).cumsum() * 0.02 + trend * np.arange(n)
+    from tempo_amd import _lib
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    out = ops.range_stats(None, _dev(ts), _dev(x), None, 1, 1000)
+    torch.cuda.synchronize()
+    launched = {name for name, _, _ in _lib.profile_read()}
+    _lib.profile_reset()
+    short = ops.range_stats(None, _dev(ts), _dev(x), None, 1, 5)       # 500-row frames: region kernel only
+    torch.cuda.synchronize()
+    launched_short = {name for name, _, _ in _lib.profile_read()}
+    _lib.profile_enable(False)
+    assert any("wide_rows_kernel" in k for k in launched), launched
+    assert not any("wide_" in k for k in launched_short), launched_short
+    del short
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    assert np.array_equal(g["perm"], np.arange(n))
+    cnt, mean, sd, mn, mx = _numpy_reference(ts // 1_000_000, x, 1000)
+    assert np.array_equal(g["count"], cnt) and (g["valid"] & 1).all()
+    assert np.array_equal(g["min"], mn) and np.array_equal(g["max"], mx)
+    np.testing.assert_allclose(g["mean"], mean, rtol=RTOL)
+    m = cnt > 1
+    np.testing.assert_allclose(g["stddev"][m], sd[m], rtol=RTOL, atol=1e-12 * 500)
+    np.testing.assert_allclose(g["sum"], mean * cnt, rtol=1e-9)
