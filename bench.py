@@ -143,7 +143,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-        from tempo_amd.dist import shuffle_by_key
+        from tempo_amd.dist import shuffle_by_key_start
 
     rows = args.rows
     n_left = n_right = rows // 2
@@ -160,14 +160,16 @@ def main():
         q = tq
         t = tk
         if dist is not None:
-            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column
+            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  All
+            # three exchanges are issued up front; the tick table's transfers overlap the join.
             _lib.profile_tag(0)
-            kl, (tl, pr), _, _ = shuffle_by_key(tq["key_l"], [tq["ts_l"], tq["trade_pr"]])
-            kr, (tr, bid, ask, bv, av), _, _ = shuffle_by_key(
+            p_trades = shuffle_by_key_start(tq["key_l"], [tq["ts_l"], tq["trade_pr"]])
+            p_quotes = shuffle_by_key_start(
                 tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]])
+            p_ticks = shuffle_by_key_start(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
+            kl, (tl, pr), _, _ = p_trades.wait()
+            kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
             q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
-            kk, (tt, xx, xv), _, _ = shuffle_by_key(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
-            t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
         _lib.profile_tag(1)
         # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
         # the left side and the three joined right columns, written by the merge itself
@@ -178,6 +180,9 @@ def main():
         n1 = q["ts_l"].numel() + q["ts_r"].numel()
         del j
         _lib.profile_tag(2)
+        if dist is not None:
+            kk, (tt, xx, xv), _, _ = p_ticks.wait()
+            t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
         out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
         n2 = t["ts"].numel()
         del out
