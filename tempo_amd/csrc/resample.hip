@@ -13,6 +13,8 @@ namespace tmp {
 
 constexpr int RB_ROWS = 1024;
 constexpr int RB_THREADS = 256;
+constexpr int BB_TILE = 4096;       // rows per tile of the big-bucket path
+constexpr int64_t BB_BIG = 32768;   // buckets longer than this are cut into tiles
 
 __device__ __forceinline__ bool bucket_head(const uint64_t *comp, int64_t i, const Layout &lay,
                                             int64_t dur) {
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
     int64_t lo = bstart[b], hi = bstart[b + 1];
+    if (hi - lo > BB_BIG) continue;  // cut into tiles by the big-bucket kernels
     for (int k = 0; k < n_cols; ++k) {
       const uint8_t *valid = cols.valid[k];
       const bool is_i = cols.is_i64[k];
@@ -244,6 +247,205 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Big buckets.  A bucket of more than BB_BIG rows is not given to one wave: the ordered rows
+// are cut into tiles of BB_TILE, one wave reduces the part of a big bucket inside its tile to
+// (count, sum, integer sum, min, max, mean, M2), and one wave per big bucket merges its tiles
+// (sums add, min / max compare, (count, mean, M2) by the pairwise variance update).  A tile
+// meets at most two big buckets -- the one holding its first row and the one holding its last.
+// ------------------------------------------------------------------------------------------
+struct BigAgg {
+  double sum, mean, m2;
+  int64_t cnt;
+  uint64_t isum, mn, mx;  // min / max as raw cell bits
+  int32_t have;
+  int32_t pad;
+};
+
+__device__ __forceinline__ void agg_merge(BigAgg &a, const BigAgg &b, bool is_i) {
+  if (!b.have) return;
+  if (!a.have) { a = b; return; }
+  if (is_i) {
+    if ((int64_t)b.mn < (int64_t)a.mn) a.mn = b.mn;
+    if ((int64_t)b.mx > (int64_t)a.mx) a.mx = b.mx;
+  } else {
+    if (dlt(__longlong_as_double((long long)b.mn), __longlong_as_double((long long)a.mn))) a.mn = b.mn;
+    if (dlt(__longlong_as_double((long long)a.mx), __longlong_as_double((long long)b.mx))) a.mx = b.mx;
+  }
+  const double na = (double)a.cnt, nb = (double)b.cnt, nn = na + nb;
+  const double delta = b.mean - a.mean;
+  a.mean += delta * (nb / nn);
+  a.m2 += b.m2 + delta * delta * (na * nb / nn);
+  a.sum += b.sum;
+  a.isum += b.isum;
+  a.cnt += b.cnt;
+}
+
+__device__ __forceinline__ BigAgg agg_shfl_down(const BigAgg &a, int off) {
+  BigAgg r;
+  r.sum = __shfl_down(a.sum, off, 64);
+  r.mean = __shfl_down(a.mean, off, 64);
+  r.m2 = __shfl_down(a.m2, off, 64);
+  r.cnt = __shfl_down(a.cnt, off, 64);
+  r.isum = __shfl_down(a.isum, off, 64);
+  r.mn = __shfl_down(a.mn, off, 64);
+  r.mx = __shfl_down(a.mx, off, 64);
+  r.have = __shfl_down(a.have, off, 64);
+  r.pad = 0;
+  return r;
+}
+
+// Rows [lo, hi) of column k, lanes striding, reduced over the wave; lane 0 holds the result.
+__device__ __forceinline__ BigAgg agg_rows(const uint32_t *perm, const ColPtrs &cols, int k, int64_t lo,
+                                           int64_t hi, int lane) {
+  const uint8_t *valid = cols.valid[k];
+  const bool is_i = cols.is_i64[k];
+  const int64_t *ci = (const int64_t *)cols.col[k];
+  const double *cd = (const double *)cols.col[k];
+  // pivot for the squared deviations: the first row's value when it is usable
+  double pivot = 0.0;
+  {
+    uint32_t r0 = perm[lo];
+    if (!valid || valid[r0]) {
+      double v = is_i ? (double)ci[r0] : cd[r0];
+      if (__builtin_isfinite(v)) pivot = v;
+    }
+  }
+  BigAgg a;
+  a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
+  double sd = 0.0, sq = 0.0;
+  for (int64_t j = lo + lane; j < hi; j += 64) {
+    uint32_t r = perm[j];
+    if (valid && !valid[r]) continue;
+    double v;
+    uint64_t bits;
+    if (is_i) {
+      int64_t iv = ci[r];
+      v = (double)iv;
+      bits = (uint64_t)iv;
+      a.isum += bits;
+      if (!a.have || iv < (int64_t)a.mn) a.mn = bits;
+      if (!a.have || iv > (int64_t)a.mx) a.mx = bits;
+    } else {
+      v = cd[r];
+      bits = (uint64_t)__double_as_longlong(v);
+      if (!a.have || dlt(v, __longlong_as_double((long long)a.mn))) a.mn = bits;
+      if (!a.have || dlt(__longlong_as_double((long long)a.mx), v)) a.mx = bits;
+    }
+    a.have = 1;
+    ++a.cnt;
+    a.sum += v;
+    const double d = v - pivot;
+    sd += d;
+    sq += d * d;
+  }
+  if (a.cnt > 0) {
+    const double n = (double)a.cnt;
+    a.mean = pivot + sd / n;
+    a.m2 = sq - sd * sd / n;
+    if (a.m2 < 0.0) a.m2 = 0.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    BigAgg o = agg_shfl_down(a, off);
+    agg_merge(a, o, is_i);
+  }
+  return a;
+}
+
+// part[(tile * 2 + slot) * n_cols + k]; slot 0: the big bucket holding the tile's first row,
+// slot 1: the big bucket holding its last row when that is another one.
+__global__ __launch_bounds__(RB_THREADS) void bucket_big_tiles_kernel(const uint32_t *perm,
+                                                                      const uint32_t *bstart,
+                                                                      const int64_t *count, int64_t n,
+                                                                      int n_cols, ColPtrs cols,
+                                                                      BigAgg *part) {
+  const int64_t nb = *count;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t tiles = (n + BB_TILE - 1) / BB_TILE;
+  for (int64_t t = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); t < tiles; t += waves) {
+    const int64_t r0 = t * BB_TILE, r1 = r0 + BB_TILE < n ? r0 + BB_TILE : n;
+    for (int slot = 0; slot < 2; ++slot) {
+      const int64_t row = slot == 0 ? r0 : r1 - 1;
+      // the bucket holding `row`: last b with bstart[b] <= row
+      int64_t lo = 0, hi = nb;
+      while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)bstart[mid] <= row) lo = mid + 1;
+        else hi = mid;
+      }
+      const int64_t b = lo - 1;
+      const int64_t blo = bstart[b], bhi = bstart[b + 1];
+      const bool big = bhi - blo > BB_BIG;
+      const bool dup = slot == 1 && blo <= r0;  // same bucket as slot 0
+      const int64_t s0 = blo > r0 ? blo : r0, s1 = bhi < r1 ? bhi : r1;
+      for (int k = 0; k < n_cols; ++k) {
+        BigAgg a;
+        a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
+        if (big && !dup) a = agg_rows(perm, cols, k, s0, s1, lane);
+        if (lane == 0) part[(size_t)(t * 2 + slot) * n_cols + k] = a;
+      }
+    }
+  }
+}
+
+// One wave per big bucket: merge its tiles' parts; lane 0 holds the result for column k.
+__device__ __forceinline__ BigAgg agg_bucket(const BigAgg *part, int n_cols, int k, bool is_i, int64_t lo,
+                                             int64_t hi, int lane) {
+  const int64_t t0 = lo / BB_TILE, t1 = (hi - 1) / BB_TILE;
+  BigAgg a;
+  a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
+  for (int64_t t = t0 + lane; t <= t1; t += 64) {
+    // in its first tile the bucket is slot 0 only if it holds that tile's first row
+    const int slot = (t == t0 && lo > t * BB_TILE) ? 1 : 0;
+    agg_merge(a, part[(size_t)(t * 2 + slot) * n_cols + k], is_i);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    BigAgg o = agg_shfl_down(a, off);
+    agg_merge(a, o, is_i);
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(RB_THREADS) void bucket_big_reduce_kernel(const uint32_t *bstart,
+                                                                       const int64_t *count, int func,
+                                                                       int n_cols, ColPtrs cols,
+                                                                       const BigAgg *part, int64_t cap,
+                                                                       double *out_f64, int64_t *out_i64,
+                                                                       uint8_t *out_valid) {
+  const int64_t nb = *count;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // 64 buckets are tested at a time, one per lane; the big ones among them are then merged by
+  // the whole wave, one after the other
+  for (int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; base < nb; base += waves * 64) {
+    const int64_t mine = base + lane;
+    uint64_t todo = __ballot(mine < nb && (int64_t)bstart[mine + 1] - (int64_t)bstart[mine] > BB_BIG);
+    for (; todo; todo &= todo - 1) {
+    const int64_t b = base + (__ffsll((long long)todo) - 1);
+    const int64_t lo = bstart[b], hi = bstart[b + 1];
+    for (int k = 0; k < n_cols; ++k) {
+      const bool is_i = cols.is_i64[k];
+      BigAgg a = agg_bucket(part, n_cols, k, is_i, lo, hi, lane);
+      if (lane == 0) {
+        int64_t o = (int64_t)k * cap + b;
+        out_valid[o] = a.cnt > 0;
+        double f = 0.0;
+        int64_t iv = 0;
+        if (a.cnt > 0) {
+          const uint64_t best = func == TMP_FUNC_MIN ? a.mn : a.mx;
+          if (func == TMP_FUNC_MEAN) f = a.sum / (double)a.cnt;
+          else if (is_i) iv = (int64_t)best;
+          else f = __longlong_as_double((long long)best);
+        }
+        out_f64[o] = f;
+        out_i64[o] = iv;
+      }
+    }
+    }
+  }
+}
+
 // withGroupedStats: one wave per bucket; per column a first sweep for count / sum / min / max
 // and a second one, around the mean just found, for the sum of squared deviations.
 struct StatsOut {
@@ -265,6 +467,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
     const int64_t lo = bstart[b], hi = bstart[b + 1];
+    if (hi - lo > BB_BIG) continue;  // cut into tiles by the big-bucket kernels
     for (int k = 0; k < n_cols; ++k) {
       const uint8_t *valid = cols.valid[k];
       const bool is_i = cols.is_i64[k];
@@ -354,19 +557,55 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t
   }
 }
 
+__global__ __launch_bounds__(RB_THREADS) void bucket_big_stats_kernel(const uint32_t *bstart,
+                                                                      const int64_t *count, int n_cols,
+                                                                      ColPtrs cols, const BigAgg *part,
+                                                                      int64_t cap, StatsOut o) {
+  const int64_t nb = *count;
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64; base < nb; base += waves * 64) {
+    const int64_t mine = base + lane;
+    uint64_t todo = __ballot(mine < nb && (int64_t)bstart[mine + 1] - (int64_t)bstart[mine] > BB_BIG);
+    for (; todo; todo &= todo - 1) {
+    const int64_t b = base + (__ffsll((long long)todo) - 1);
+    const int64_t lo = bstart[b], hi = bstart[b + 1];
+    for (int k = 0; k < n_cols; ++k) {
+      const bool is_i = cols.is_i64[k];
+      BigAgg a = agg_bucket(part, n_cols, k, is_i, lo, hi, lane);
+      if (lane == 0) {
+        const int64_t at = (int64_t)k * cap + b;
+        const int64_t n = a.cnt;
+        o.n[at] = n;
+        o.mean[at] = n > 0 ? a.sum / (double)n : 0.0;
+        double sd = 0.0;
+        if (n > 1) sd = a.m2 != a.m2 ? a.m2 : sqrt((a.m2 < 0.0 ? 0.0 : a.m2) / (double)(n - 1));
+        o.stddev[at] = sd;
+        o.mn[at] = n > 0 ? a.mn : 0ull;
+        o.mx[at] = n > 0 ? a.mx : 0ull;
+        o.sum[at] = n > 0 ? (is_i ? a.isum : (uint64_t)__double_as_longlong(a.sum)) : 0ull;
+      }
+    }
+    }
+  }
+}
+
 struct RbPlan {
   OrderBuffers ob;
   uint32_t *block_counts;
   uint32_t *bstart;
+  BigAgg *part;  // [tiles][2][n_cols] partial aggregates of big buckets
   int nblocks;
 };
 
-static void rb_plan(int64_t n, Workspace &ws, RbPlan *p) {
+static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p) {
   order_plan(n, ws, &p->ob);
   size_t cnt = (size_t)(n > 0 ? n : 1);
   p->nblocks = (int)((cnt + RB_ROWS - 1) / RB_ROWS);
   p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
   p->bstart = ws.take<uint32_t>(cnt + 1);
+  size_t tiles = (cnt + BB_TILE - 1) / BB_TILE;
+  p->part = ws.take<BigAgg>(tiles * 2 * (size_t)(n_cols > 0 ? n_cols : 1));
 }
 
 }  // namespace tmp
@@ -377,7 +616,7 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p);
   return ws.off;
 }
 
@@ -403,7 +642,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -426,9 +665,17 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
              p.block_counts, p.bstart, a->out_key, a->out_start);
   if (reduce) {
-    if (a->n_cols > 0)
+    if (a->n_cols > 0) {
       TMP_LAUNCH(bucket_reduce_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
                  p.bstart, a->out_count, a->func, a->n_cols, cp, a->n, a->out_f64, a->out_i64, a->out_valid);
+      if (a->n > BB_BIG) {  // only then can a bucket be a big one
+        TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
+                   dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part);
+        TMP_LAUNCH(bucket_big_reduce_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
+                   dim3(RB_THREADS), st, p.bstart, a->out_count, a->func, a->n_cols, cp, p.part, a->n,
+                   a->out_f64, a->out_i64, a->out_valid);
+      }
+    }
   } else {
     TMP_LAUNCH(bucket_pick_kernel, dim3(grid_for(a->n, RB_THREADS * 4, 8192)), dim3(RB_THREADS), st, res.comp,
                res.perm, lay, p.bstart, a->out_count, a->func, a->n_cols, cp, a->out_row);
@@ -441,7 +688,7 @@ extern "C" size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p);
   return ws.off;
 }
 
@@ -464,7 +711,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
               TMP_EINVAL, "tmp_grouped_stats: column or output arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -492,6 +739,12 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     o.sum = (uint64_t *)a->out_sum; o.stddev = a->out_stddev;
     TMP_LAUNCH(bucket_stats_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
                p.bstart, a->out_count, a->n_cols, cp, a->n, o);
+    if (a->n > BB_BIG) {
+      TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
+                 dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part);
+      TMP_LAUNCH(bucket_big_stats_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
+                 dim3(RB_THREADS), st, p.bstart, a->out_count, a->n_cols, cp, p.part, a->n, o);
+    }
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

@@ -293,3 +293,47 @@ def test_interpolate_edges(orc, ops):
     # rows closer than the frequency are rejected, as Spark's sequence() rejects them
     with pytest.raises(ValueError, match="closer than freq_us"):
         ops.interpolate(None, _dev(np.array([0, 10, 20], np.int64)), 1, 15, "zero", [], [])
+
+
+@pytest.mark.parametrize("func", ["mean", "min", "max"])
+def test_resample_big_buckets(orc, ops, func):
+    """Buckets of more than 32 768 rows are cut into tiles and merged: day buckets over an
+    intraday series, next to small buckets in the same call."""
+    rng = np.random.default_rng(21)
+    n, nk = 400_000, 3
+    key = rng.integers(0, nk, n).astype(np.int32)
+    day = 86_400_000_000
+    ts = 1_596_240_000_000_000 + rng.integers(0, 3 * day, n)
+    ts[key == 2] = 1_596_240_000_000_000 + rng.integers(0, 200, (key == 2).sum()) * day   # key 2: tiny buckets
+    xd = 50 + np.cumsum(rng.normal(0, 0.01, n))
+    xi = rng.integers(-10**9, 10**9, n)
+    vd = (rng.random(n) > 0.1).astype(np.uint8)
+    r = ops.resample(_dev(key), _dev(ts), nk, day, func, [_dev(xd), _dev(xi)], [_dev(vd), None])
+    e = orc.resample(key, ts, day, func, [xd, xi], [vd, None])
+    assert r["n"] == e["n"] and np.array_equal(r["start"].cpu().numpy(), e["start"])
+    assert np.array_equal(r["valid"].cpu().numpy(), e["valid"])
+    if func == "mean":
+        np.testing.assert_allclose(r["f64"].cpu().numpy(), e["f64"], rtol=1e-9)
+    else:
+        assert np.array_equal(r["f64"].cpu().numpy()[0], e["f64"][0])
+        assert np.array_equal(r["i64"].cpu().numpy()[1], e["i64"][1])
+
+
+def test_grouped_stats_big_buckets(orc, ops):
+    rng = np.random.default_rng(22)
+    n = 300_000
+    day = 86_400_000_000
+    ts = 1_596_240_000_000_000 + np.sort(rng.integers(0, 2 * day, n))
+    xd = 1000 + np.cumsum(rng.normal(0, 0.01, n)) + 0.001 * np.arange(n)
+    xi = rng.integers(-10**12, 10**12, n)
+    vd = (rng.random(n) > 0.2).astype(np.uint8)
+    r = ops.grouped_stats(None, _dev(ts), 1, day, [_dev(xd), _dev(xi)], [_dev(vd), None])
+    e = orc.grouped_stats(None, ts, day, [xd, xi], [vd, None])
+    assert r["n"] == e["n"] == 2
+    for c in range(2):
+        assert np.array_equal(r["count"][c].cpu().numpy(), e["count"][c])
+        assert np.array_equal(r["min"][c].cpu().numpy(), e["min"][c]) and np.array_equal(r["max"][c].cpu().numpy(), e["max"][c])
+        np.testing.assert_allclose(r["mean"][c].cpu().numpy(), e["mean"][c], rtol=1e-9)
+        np.testing.assert_allclose(r["stddev"][c].cpu().numpy(), e["stddev"][c], rtol=1e-9)
+    assert np.array_equal(r["sum"][1].cpu().numpy(), e["sum"][1])
+    np.testing.assert_allclose(r["sum"][0].cpu().numpy(), e["sum"][0], rtol=1e-9)
