@@ -25,6 +25,8 @@ def short(name):
     if base == "radix_scatter_kernel":
         npay = args.split(",")[2].strip()
         return base + ("+payload" if npay != "0" else "")
+    if base == "radix_hist_kernel":
+        return base + ("+words" if args.split(",")[-1].strip() in ("true", "1") else "")
     if base == "range_stats_kernel":
         return "range_stats_kernel<T>"
     if base == "gather_kernel":

@@ -157,24 +157,36 @@ struct MaskPtrs {
   const uint8_t *p[TMP_MAX_MASKS];
 };
 
-__global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, const int32_t *key,
-                                                           const int64_t *ts,
-                                                           const int64_t *seq,
-                                                           const uint8_t *seq_valid, Layout lay,
-                                                           int n_masks, MaskPtrs masks,
-                                                           uint64_t *comp, uint32_t *idx) {
+// Everything needed to build the sort word of input row i.
+struct GenArgs {
+  const int32_t *key;
+  const int64_t *ts;
+  const int64_t *seq;
+  const uint8_t *seq_valid;
+  Layout lay;
+  int n_masks;
+  MaskPtrs masks;
+};
+
+__device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
+  const Layout &lay = g.lay;
+  int64_t p = lay.prim_div == 1 ? g.ts[i] : floordiv_i64(g.ts[i], lay.prim_div);
+  uint64_t w = (uint64_t)(p - lay.prim_min) << lay.prim_shift();
+  if (lay.key_bits) w |= (uint64_t)(uint32_t)g.key[i] << lay.key_shift();
+  if (lay.seq_bits && g.seq) {
+    bool sv = !g.seq_valid || g.seq_valid[i];
+    if (sv) w |= (uint64_t)(g.seq[i] - lay.seq_min + 1) << lay.seq_shift();
+  }
+  for (int m = 0; m < g.n_masks; ++m)
+    if (!g.masks.p[m] || g.masks.p[m][i]) w |= 1ull << m;
+  return w;
+}
+
+__global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, GenArgs g, uint64_t *comp,
+                                                           uint32_t *idx) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int64_t p = lay.prim_div == 1 ? ts[i] : floordiv_i64(ts[i], lay.prim_div);
-    uint64_t w = (uint64_t)(p - lay.prim_min) << lay.prim_shift();
-    if (lay.key_bits) w |= (uint64_t)(uint32_t)key[i] << lay.key_shift();
-    if (lay.seq_bits && seq) {
-      bool sv = !seq_valid || seq_valid[i];
-      if (sv) w |= (uint64_t)(seq[i] - lay.seq_min + 1) << lay.seq_shift();
-    }
-    for (int m = 0; m < n_masks; ++m)
-      if (!masks.p[m] || masks.p[m][i]) w |= 1ull << m;
-    comp[i] = w;
+    comp[i] = make_word(g, i);
     if (idx) idx[i] = (uint32_t)i;
   }
 }
@@ -203,11 +215,14 @@ static SortGeom sort_geom(int64_t n, int tile) {
   return g;
 }
 
-template <int RS_THREADS, int RS_ITEMS, int RS_BITS>
+// GEN: the launch is the first pass's histogram and builds the sort words on the way (it writes
+// them to `words`; the row ids of a first pass are the positions and are never stored).
+template <int RS_THREADS, int RS_ITEMS, int RS_BITS, bool GEN>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
-                                                                uint32_t *counts) {
+                                                                uint32_t *counts, GenArgs gen,
+                                                                uint64_t *words) {
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   constexpr int RS_RADIX = 1 << RS_BITS;
@@ -219,7 +234,14 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
   if (end > n) end = n;
   int wave = threadIdx.x >> 6;
   for (int64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
-    uint32_t d = (uint32_t)(keys[i] >> shift) & mask;
+    uint64_t w;
+    if (GEN) {
+      w = make_word(gen, i);
+      words[i] = w;
+    } else {
+      w = keys[i];
+    }
+    uint32_t d = (uint32_t)(w >> shift) & mask;
     atomicAdd(&hist[wave][d], 1u);
   }
   __syncthreads();
@@ -301,7 +323,8 @@ int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
 // NPAY > 0: the pass also moves up to NPAY 8-byte payload columns, read through the row id
 // (src[row id]) and written next to the pair -- used on the last pass so that ordered copies
 // of payload columns cost no separate random gather (the scatter writes them in digit runs).
-template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS>
+// FIRST: the pass is the first one, its row ids are the positions themselves (not read).
+template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       int64_t g = base0 + wave * (64 * RS_ITEMS) + it * 64 + lane;
       bool valid = g < n;
       kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
-      vn[PREFETCH ? it : 0] = valid ? vin[g] : 0u;
+      vn[PREFETCH ? it : 0] = valid ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
     }
   }
   for (int t = 0; t < tiles_per_block; ++t) {
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
           int64_t g = next_base + wave * (64 * RS_ITEMS) + it * 64 + lane;
           bool valid = g < n;
           kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
-          vn[PREFETCH ? it : 0] = valid ? vin[g] : 0u;
+          vn[PREFETCH ? it : 0] = valid ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
         }
       }
     } else {
@@ -463,7 +486,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
       int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-      if (!PAY) v[it] = pos < tile_n ? vin[tile_base + pos] : 0u;
+      if (!PAY) v[it] = pos < tile_n ? (FIRST ? (uint32_t)(tile_base + pos) : vin[tile_base + pos]) : 0u;
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -558,41 +581,56 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
   return TMP_OK;
 }
 
-// One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.
+// One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.  gen != nullptr: the
+// pass is the first one over freshly laid out rows -- its histogram kernel builds the sort words
+// (into b.comp[cur]) and its row ids are the positions.
 template <int THREADS, int ITEMS, int NPAY, int BITS>
 static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                             const PayPtrs &pp) {
+                             const PayPtrs &pp, const GenArgs *gen, bool hist_done) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   uint32_t mask = (1u << nbits) - 1;
-  {
-    ProfScope ps("radix_hist_kernel", st);
-    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS>), dim3(g.grid), dim3(THREADS), 0, st,
-                       b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts);
+  GenArgs none;
+  memset(&none, 0, sizeof(none));
+  if (!hist_done) {
+    ProfScope ps(gen ? "radix_hist_kernel+words" : "radix_hist_kernel", st);
+    if (gen)
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, true>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
+    else
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, false>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr);
+    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid);
   }
-  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid);
   {
     ProfScope ps(NPAY == 0 ? "radix_scatter_kernel" : "radix_scatter_kernel+payload", st);
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS>), dim3(g.grid), dim3(THREADS), 0, st,
-                       b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                       g.tiles_per_block, b.counts, pp);
+    if (gen)
+      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true>), dim3(g.grid), dim3(THREADS), 0,
+                         st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                         g.tiles_per_block, b.counts, pp);
+    else
+      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, false>), dim3(g.grid), dim3(THREADS), 0,
+                         st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                         g.tiles_per_block, b.counts, pp);
   }
 }
 
 template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                           const PayPtrs &pp) {
-  if (nbits <= 8) radix_one_pass_t<THREADS, ITEMS, NPAY, 8>(b, n, cur, lo, nbits, st, pp);
-  else radix_one_pass_t<THREADS, ITEMS, NPAY, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp);
+                           const PayPtrs &pp, const GenArgs *gen, bool hist_done) {
+  if (nbits <= 8) radix_one_pass_t<THREADS, ITEMS, NPAY, 8>(b, n, cur, lo, nbits, st, pp, gen, hist_done);
+  else radix_one_pass_t<THREADS, ITEMS, NPAY, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, gen, hist_done);
 }
 
-// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0].  Digits are
+// Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0] -- or, with
+// `gen`, of the rows themselves: the first pass then lays out the sort words on the way and
+// takes the positions as row ids (lo_bit < hi_bit is the caller's business then).  Digits are
 // 8 bits wide, or a mix of 8 and 9 where that takes one pass fewer.  With payload columns the
 // last pass also delivers out[c][p] = src[c][perm[p]] (one column per launch; more columns
 // replay the last pass); *carried tells whether a pass ran at all (no pass: the order is the
 // identity and the outputs are untouched).
-int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
-                       hipStream_t st, int n_pay, const uint64_t *const *pay_src,
-                       uint64_t *const *pay_out, bool *carried) {
+static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                        hipStream_t st, int n_pay, const uint64_t *const *pay_src,
+                        uint64_t *const *pay_out, bool *carried, const GenArgs *gen) {
   int cur = 0;
   if (carried) *carried = false;
   PayPtrs none;
@@ -605,17 +643,19 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
     // spread the bits evenly: the first (total % passes) digits are one bit wider
     int nbits = total / passes + (p < total % passes ? 1 : 0);
     bool last = p + 1 == passes;
+    const GenArgs *g = p == 0 ? gen : nullptr;
     if (last && n_pay > 0) {
       for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
         PayPtrs pp;
         memset(&pp, 0, sizeof(pp));
         pp.n = n_pay - c0 < kMaxPay ? n_pay - c0 : kMaxPay;
         for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
-        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp);
+        // a replay for further columns reuses the offsets of the first launch
+        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, c0 > 0);
       }
       if (carried) *carried = true;
     } else {
-      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none);
+      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none, g, false);
     }
     lo += nbits;
     cur ^= 1;
@@ -626,6 +666,12 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
   return TMP_OK;
 }
 
+int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
+                       hipStream_t st, int n_pay, const uint64_t *const *pay_src,
+                       uint64_t *const *pay_out, bool *carried) {
+  return radix_passes(b, n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr);
+}
+
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st, int n_pay, const uint64_t *const *pay_src,
                 uint64_t *const *pay_out, bool *carried) {
@@ -633,15 +679,20 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   res->comp = b.comp[0];
   res->perm = b.idx[0];
   if (s.n <= 0) return TMP_OK;
-  MaskPtrs mp;
-  for (int m = 0; m < TMP_MAX_MASKS; ++m) mp.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
-  int grid = grid_for(s.n, kBlock * 4, 8192);
-  TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts, s.seq,
-                     s.seq_valid, lay, s.n_masks, mp, b.comp[0], b.idx[0]);
-  TMP_CHECK_HIP(hipGetLastError());
-  if (sorted == 1) return TMP_OK;
-  return order_radix_passes(b, s.n, sorted == 2 ? lay.key_shift() : lay.low_bits, lay.total_bits(), res, st,
-                            n_pay, pay_src, pay_out, carried);
+  GenArgs gen;
+  memset(&gen, 0, sizeof(gen));
+  gen.key = s.key; gen.ts = s.ts; gen.seq = s.seq; gen.seq_valid = s.seq_valid;
+  gen.lay = lay;
+  gen.n_masks = s.n_masks;
+  for (int m = 0; m < TMP_MAX_MASKS; ++m) gen.masks.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
+  const int lo_bit = sorted == 2 ? lay.key_shift() : lay.low_bits, hi_bit = lay.total_bits();
+  if (sorted == 1 || lo_bit >= hi_bit) {  // no pass to run: the words in input order are the result
+    int grid = grid_for(s.n, kBlock * 4, 8192);
+    TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, gen, b.comp[0], b.idx[0]);
+    TMP_CHECK_HIP(hipGetLastError());
+    return TMP_OK;
+  }
+  return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
