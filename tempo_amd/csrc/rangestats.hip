@@ -25,7 +25,10 @@ constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
 constexpr int RK_SB = 8;                 // slots per sub-block (half a DPP row)
 constexpr int RK_NSB = RK_CAP / RK_SB;  // 320
-constexpr int RK_LEVELS = 8;            // spans up to 128 sub-blocks; longer runs use three spans
+constexpr int RK_GRP = 16;              // sub-blocks per group (one DPP row of lanes)
+constexpr int RK_NGRP = RK_NSB / RK_GRP;  // 20
+constexpr int RK_GLEVELS = 5;           // sparse table over the groups: spans up to 16 of them
+static_assert(RK_NSB % 64 == 0 && RK_NGRP <= 32, "group scans are laid out for whole waves");
 
 // ---- 8-lane inclusive scans inside a DPP row (row_shr 1, 2, 4): lanes 7 and 15 of every row
 //      end up with the totals of their 8-lane halves.
@@ -116,6 +119,21 @@ struct MinMax<int64_t> {
   }
 };
 
+// Inclusive scans of min / max along a 16-lane DPP row: forward (row_shr 1, 2, 4, 8) gives every
+// lane the extreme of its row up to itself, backward (row_shl) from itself to the row's end.
+template <int CTRL>
+__device__ __forceinline__ double dpp_any(double v) { return dpp_f64<CTRL>(v, false); }
+template <int CTRL>
+__device__ __forceinline__ int64_t dpp_any(int64_t v) { return (int64_t)dpp_u64<CTRL>((uint64_t)v, false); }
+template <typename T, bool MIN, bool FWD>
+__device__ __forceinline__ T group_scan(T v) {
+#define G_(c) { T t = dpp_any<c>(v); v = MIN ? MinMax<T>::mn(v, t) : MinMax<T>::mx(v, t); }
+  if (FWD) { G_(0x111) G_(0x112) G_(0x114) G_(0x118) }
+  else { G_(0x101) G_(0x102) G_(0x104) G_(0x108) }
+#undef G_
+  return v;
+}
+
 constexpr uint32_t RK_SAT = 0x7fffffffu;  // saturated relative sort word
 
 // One staged slot of a double metric into the frame's running sums; NULL slots hold NaN.
@@ -139,8 +157,11 @@ struct RsShared {
   double bq[RK_NSB + 1];     // ... of sum((x - pivot)^2)
   uint64_t bi[kIntT ? RK_NSB + 1 : 1];  // ... of the exact integer sum (int64 metrics)
   uint32_t bc[RK_NSB + 1];   // ... of counts: low 16 bits valid, high 16 bits non-finite
-  T mn[RK_LEVELS][RK_NSB];   // sparse tables over sub-block minima / maxima
-  T mx[RK_LEVELS][RK_NSB];
+  // min / max of whole sub-blocks: per sub-block its own value, the extreme of its group of 16
+  // up to it and from it on, and a small sparse table over the group extremes
+  T mn0[RK_NSB], mx0[RK_NSB];
+  T mn_pre[RK_NSB], mn_suf[RK_NSB], mx_pre[RK_NSB], mx_suf[RK_NSB];
+  T gmn[RK_GLEVELS][32], gmx[RK_GLEVELS][32];
   int pivot_at;
   int nonfinite;  // some staged value is NaN or +-inf
 };
@@ -223,8 +244,8 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
         s.bq[b + 1] = sq;
         s.bc[b + 1] = sc;
         if (kInt) s.bi[b + 1] = si;
-        s.mn[0][b] = vmn;
-        s.mx[0][b] = vmx;
+        s.mn0[b] = vmn;
+        s.mx0[b] = vmx;
       }
     }
   }
@@ -277,19 +298,36 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       s.bs[0] = 0.0; s.bq[0] = 0.0; s.bc[0] = 0u;
       if (kInt) s.bi[0] = 0ull;
     }
-  } else if (wave == 1 || wave == 2) {
-    // one wave per table; a wavefront-scope fence between levels keeps the level just written
-    // visible to the lanes that read it next (plain LDS accesses: volatile ones would be
-    // emitted as flat operations)
-    for (int lv = 1; lv < RK_LEVELS; ++lv) {
-      int span = 1 << lv;
-      for (int b = lane; b + span <= RK_NSB; b += 64) {
-        if (wave == 1) s.mn[lv][b] = MinMax<T>::mn(s.mn[lv - 1][b], s.mn[lv - 1][b + span / 2]);
-        else s.mx[lv][b] = MinMax<T>::mx(s.mx[lv - 1][b], s.mx[lv - 1][b + span / 2]);
+  } else if (wave <= 2 * (RK_NSB / 64)) {
+    // waves 1..5: group scans of the minima, waves 6..10: of the maxima; lane = sub-block
+    const bool is_min = wave <= RK_NSB / 64;
+    const int b = ((wave - 1) % (RK_NSB / 64)) * 64 + lane;
+    if (is_min) {
+      const T v = s.mn0[b];
+      const T pre = group_scan<T, true, true>(v);
+      s.mn_pre[b] = pre;
+      s.mn_suf[b] = group_scan<T, true, false>(v);
+      if ((lane & 15) == 15) s.gmn[0][b / RK_GRP] = pre;
+    } else {
+      const T v = s.mx0[b];
+      const T pre = group_scan<T, false, true>(v);
+      s.mx_pre[b] = pre;
+      s.mx_suf[b] = group_scan<T, false, false>(v);
+      if ((lane & 15) == 15) s.gmx[0][b / RK_GRP] = pre;
+    }
+  }
+  __syncthreads();
+  // sparse table over the group extremes, in registers: wave 0 the minima, wave 1 the maxima
+  if (wave < 2) {
+    T v = lane < RK_NGRP ? (wave == 0 ? s.gmn[0][lane] : s.gmx[0][lane])
+                         : (wave == 0 ? MinMax<T>::min_identity() : MinMax<T>::max_identity());
+    for (int lv = 1; lv < RK_GLEVELS; ++lv) {
+      T t = __shfl_down(v, 1 << (lv - 1), 64);
+      v = wave == 0 ? MinMax<T>::mn(v, t) : MinMax<T>::mx(v, t);
+      if (lane < 32) {
+        if (wave == 0) s.gmn[lv][lane] = v;
+        else s.gmx[lv][lane] = v;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   __syncthreads();
@@ -371,14 +409,22 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       sq += s.bq[m1 + 1] - s.bq[m0];
       dc += s.bc[m1 + 1] - s.bc[m0];
       if (kInt) isum += s.bi[m1 + 1] - s.bi[m0];
-      int lv = 31 - __clz(m1 - m0 + 1);
-      if (lv > RK_LEVELS - 1) {  // more than 255 whole sub-blocks: a third span covers the middle
-        lv = RK_LEVELS - 1;
-        mn = MinMax<T>::mn(mn, s.mn[lv][m0 + (1 << lv)]);
-        mx = MinMax<T>::mx(mx, s.mx[lv][m0 + (1 << lv)]);
+      const int g0 = m0 / RK_GRP, g1 = m1 / RK_GRP;
+      if (g0 == g1) {  // inside one group: its sub-blocks one by one (at most 16)
+        for (int sbk = m0; sbk <= m1; ++sbk) {
+          mn = MinMax<T>::mn(mn, s.mn0[sbk]);
+          mx = MinMax<T>::mx(mx, s.mx0[sbk]);
+        }
+      } else {
+        mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.mn_suf[m0], s.mn_pre[m1]));
+        mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.mx_suf[m0], s.mx_pre[m1]));
+        const int inner = g1 - g0 - 1;  // whole groups in between
+        if (inner > 0) {
+          const int lv = 31 - __clz(inner);
+          mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.gmn[lv][g0 + 1], s.gmn[lv][g1 - (1 << lv)]));
+          mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.gmx[lv][g0 + 1], s.gmx[lv][g1 - (1 << lv)]));
+        }
       }
-      mn = MinMax<T>::mn(mn, MinMax<T>::mn(s.mn[lv][m0], s.mn[lv][m1 + 1 - (1 << lv)]));
-      mx = MinMax<T>::mx(mx, MinMax<T>::mx(s.mx[lv][m0], s.mx[lv][m1 + 1 - (1 << lv)]));
     }
     slow = (dc >> 16) != 0;  // a non-finite value inside the frame
   }
