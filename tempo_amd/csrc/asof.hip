@@ -535,6 +535,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   rs.n = a->n_right; rs.key = a->key_right; rs.n_keys = a->n_keys; rs.ts = a->ts_right; rs.prim_div = 1;
   rs.seq = a->seq_right; rs.seq_valid = a->seq_right_valid;
   rs.n_masks = a->n_masks;
+  ls.coarse_ok = rs.coarse_ok = 1;
   for (int m = 0; m < a->n_masks; ++m) rs.masks[m] = a->masks[m];
 
   // ranges of both sides, one host read each, then one shared bit layout
@@ -546,6 +547,8 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   RangeInfo both = rr;
   both.prim_min = rl.prim_min < rr.prim_min ? rl.prim_min : rr.prim_min;
   both.prim_max = rl.prim_max > rr.prim_max ? rl.prim_max : rr.prim_max;
+  both.not_thousands = rl.not_thousands | rr.not_thousands;
+  both.not_millions = rl.not_millions | rr.not_millions;
   Layout lay;
   OrderSpec lay_spec = rs;  // the key field exists if either side carries keys (one may be empty)
   if (!lay_spec.key) lay_spec.key = ls.key;

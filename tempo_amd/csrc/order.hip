@@ -48,6 +48,8 @@ __global__ void range_init_kernel(RangeInfo *r) {
   r->seq_max = INT64_MIN;
   r->unsorted = 0;
   r->time_unsorted = 0;
+  r->not_thousands = 0;
+  r->not_millions = 0;
 }
 
 __device__ __forceinline__ int64_t wave_min(int64_t v) {
@@ -65,13 +67,27 @@ __device__ __forceinline__ int64_t wave_max(int64_t v) {
   return v;
 }
 
+// x is a multiple of 1000 (= 8 * 125) / of 1000000 (= 64 * 15625): low bits clear and the odd
+// factor divides |x|, tested by multiplying with its inverse modulo 2^64 -- no division.
+__device__ __forceinline__ bool multiple_of_1000(int64_t x) {
+  uint64_t u = x < 0 ? 0ull - (uint64_t)x : (uint64_t)x;
+  return (u & 7ull) == 0 && u * 0x1cac083126e978d5ull <= 0x20c49ba5e353f7cull;
+}
+__device__ __forceinline__ bool multiple_of_1000000(int64_t x) {
+  uint64_t u = x < 0 ? 0ull - (uint64_t)x : (uint64_t)x;
+  return (u & 63ull) == 0 && u * 0x790fb65668c26139ull <= 0x431bde82d7b63ull;
+}
+
 __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int32_t *key,
                                                             const int64_t *ts, int64_t div,
                                                             const int64_t *seq,
                                                             const uint8_t *seq_valid,
                                                             RangeInfo *out) {
   int64_t pmin = INT64_MAX, pmax = INT64_MIN, smin = INT64_MAX, smax = INT64_MIN;
-  int bad = 0, tbad = 0;
+  int bad = 0, tbad = 0, nk = 0, nm = 0;
+  // granularity is looked for in raw timestamp columns only, and a wave stops looking once one
+  // of its lanes has met a value that is not a whole millisecond (wave-uniform branch)
+  bool gran = div == 1;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t first = 0;  // rows below `first` are covered by the four-rows-per-thread loop
   if (!seq && (((uintptr_t)ts | (uintptr_t)key) & 15) == 0) {
@@ -93,6 +109,10 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
       if (c == 0) tp = t[0];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (gran) {
+          nk |= !multiple_of_1000(t[j]);
+          nm |= !multiple_of_1000000(t[j]);
+        }
         pmin = t[j] < pmin ? t[j] : pmin;
         pmax = t[j] > pmax ? t[j] : pmax;
         bool tdown = tp > t[j];
@@ -101,10 +121,16 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
         tp = t[j];
         kp = kk[j];
       }
+      if (gran && __any(nk)) gran = false;
     }
   }
   for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
+    if (gran) {
+      nk |= !multiple_of_1000(p);
+      nm |= !multiple_of_1000000(p);
+      if (__any(nk)) gran = false;
+    }
     pmin = p < pmin ? p : pmin;
     pmax = p > pmax ? p : pmax;
     bool sv = false;
@@ -140,13 +166,20 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
   smax = wave_max(smax);
   bad = __any(bad);
   tbad = __any(tbad);
+  if (div != 1) nk = 1;
+  nk = __any(nk);
+  nm = __any(nm) | nk;
+  // Every wave reports into one small record: each field is read first and only touched by an
+  // atomic when this wave would change it, which after the first few waves is almost never.
   if ((threadIdx.x & 63) == 0) {
-    if (pmin != INT64_MAX) atomicMin((long long *)&out->prim_min, (long long)pmin);
-    if (pmax != INT64_MIN) atomicMax((long long *)&out->prim_max, (long long)pmax);
-    if (smin != INT64_MAX) atomicMin((long long *)&out->seq_min, (long long)smin);
-    if (smax != INT64_MIN) atomicMax((long long *)&out->seq_max, (long long)smax);
-    if (bad) atomicOr(&out->unsorted, 1);
-    if (tbad) atomicOr(&out->time_unsorted, 1);
+    if (pmin < __atomic_load_n(&out->prim_min, __ATOMIC_RELAXED)) atomicMin((long long *)&out->prim_min, (long long)pmin);
+    if (pmax > __atomic_load_n(&out->prim_max, __ATOMIC_RELAXED)) atomicMax((long long *)&out->prim_max, (long long)pmax);
+    if (smin < __atomic_load_n(&out->seq_min, __ATOMIC_RELAXED)) atomicMin((long long *)&out->seq_min, (long long)smin);
+    if (smax > __atomic_load_n(&out->seq_max, __ATOMIC_RELAXED)) atomicMax((long long *)&out->seq_max, (long long)smax);
+    if (bad && !__atomic_load_n(&out->unsorted, __ATOMIC_RELAXED)) atomicOr(&out->unsorted, 1);
+    if (tbad && !__atomic_load_n(&out->time_unsorted, __ATOMIC_RELAXED)) atomicOr(&out->time_unsorted, 1);
+    if (nk && !__atomic_load_n(&out->not_thousands, __ATOMIC_RELAXED)) atomicOr(&out->not_thousands, 1);
+    if (nm && !__atomic_load_n(&out->not_millions, __ATOMIC_RELAXED)) atomicOr(&out->not_millions, 1);
   }
 }
 
@@ -171,7 +204,9 @@ struct GenArgs {
 __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   const Layout &lay = g.lay;
   int64_t p = lay.prim_div == 1 ? g.ts[i] : floordiv_i64(g.ts[i], lay.prim_div);
-  uint64_t w = (uint64_t)(p - lay.prim_min) << lay.prim_shift();
+  uint64_t rel = (uint64_t)(p - lay.prim_min);
+  if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
+  uint64_t w = rel << lay.prim_shift();
   if (lay.key_bits) w |= (uint64_t)(uint32_t)g.key[i] << lay.key_shift();
   if (lay.seq_bits && g.seq) {
     bool sv = !g.seq_valid || g.seq_valid[i];
@@ -560,6 +595,9 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
   l.prim_div = s.prim_div;
   l.prim_min = r.prim_min <= r.prim_max ? r.prim_min : 0;
   uint64_t prange = r.prim_min <= r.prim_max ? (uint64_t)r.prim_max - (uint64_t)r.prim_min : 0;
+  l.prim_gran = 1;
+  if (s.coarse_ok) l.prim_gran = !r.not_millions ? 1000000 : (!r.not_thousands ? 1000 : 1);
+  prange /= (uint64_t)l.prim_gran;
   l.prim_bits = bits_for(prange);
   l.seq_bits = 0;
   l.seq_min = 0;

@@ -646,7 +646,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
-  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1;
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1; s.coarse_ok = 1;
   Layout lay;
   OrderResult res;
   TMP_TRY(order_single(s, p.ob, &lay, &res, st));
@@ -715,7 +715,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
-  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1;
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1; s.coarse_ok = 1;
   Layout lay;
   OrderResult res;
   TMP_TRY(order_single(s, p.ob, &lay, &res, st));

@@ -221,3 +221,18 @@ def test_asof_fused_table(orc, ops, skip_nulls, order):
         assert np.array_equal(vals.cpu().numpy(), want), c
     if skip_nulls:
         assert out["missing"].cpu().numpy().tolist() == omiss.tolist()
+
+
+@pytest.mark.parametrize("step_l,step_r", [(1000, 1000), (1_000_000, 1000), (1_000_000, 1_000_000), (1000, 1), (7, 1000)])
+def test_asof_timestamp_granularity(orc, ops, step_l, step_r):
+    """Whole-millisecond / whole-second microsecond columns sort on a shorter word (the time field
+    is stored in units of the common granularity); both signs of the epoch, sides that differ."""
+    rng = np.random.default_rng(step_l % 97 + step_r % 89)
+    nL, nR, nk = 30_000, 40_000, 11
+    key_l = rng.integers(0, nk, nL).astype(np.int32)
+    key_r = rng.integers(0, nk, nR).astype(np.int32)
+    ts_l = rng.integers(-3_000_000_000 // step_l, 3_000_000_000 // step_l, nL) * step_l
+    ts_r = rng.integers(-3_000_000_000 // step_r, 3_000_000_000 // step_r, nR) * step_r
+    masks = [(rng.random(nR) >= 0.2).astype(np.uint8)]
+    _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, None, None, masks), nk)
+    _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, None, None, masks), nk, ts_partition_val=30, fraction=0.3)
