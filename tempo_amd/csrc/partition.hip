@@ -23,13 +23,31 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
   __shared__ unsigned int hist[256];
   for (int i = threadIdx.x; i < 256; i += kBlock) hist[i] = 0;
   __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool few = n_parts <= 64;  // lane p of every wave counts the rows of part p in a register
+  unsigned int mine = 0;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    uint32_t o = mix_key((uint32_t)key[i]) % n_parts;
-    comp[i] = o;
-    idx[i] = (uint32_t)i;
-    atomicAdd(&hist[o], 1u);
+  const int64_t start = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // whole waves iterate together (the ballots below need every lane present)
+  for (int64_t base = start - lane; base < n; base += stride) {
+    const int64_t i = base + lane;
+    const bool in = i < n;
+    uint32_t o = 0;
+    if (in) {
+      o = mix_key((uint32_t)key[i]) % n_parts;
+      comp[i] = o;
+      idx[i] = (uint32_t)i;
+    }
+    if (few) {
+      for (uint32_t p = 0; p < n_parts; ++p) {
+        uint64_t b = __ballot(in && o == p);
+        if ((uint32_t)lane == p) mine += (unsigned int)__popcll(b);
+      }
+    } else if (in) {
+      atomicAdd(&hist[o], 1u);
+    }
   }
+  if (few && mine) atomicAdd(&hist[lane], mine);
   __syncthreads();
   for (int i = threadIdx.x; i < (int)n_parts; i += kBlock)
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
@@ -73,7 +91,7 @@ extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
   OrderBuffers b;
   order_plan(a->n, ws, &b);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_hash_partition: workspace too small");
-  TMP_LAUNCH(owner_kernel, dim3(grid_for(a->n, kBlock * 8, 4096)), dim3(kBlock), st, a->key, a->n,
+  TMP_LAUNCH(owner_kernel, dim3(grid_for(a->n, kBlock * 8, 2048)), dim3(kBlock), st, a->key, a->n,
              (uint32_t)a->n_parts, b.comp[0], b.idx[0], (unsigned long long *)a->out_counts);
   OrderResult res;
   TMP_TRY(order_radix_passes(b, a->n, 0, bits_for((uint64_t)a->n_parts - 1), &res, st));
