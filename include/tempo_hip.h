@@ -438,6 +438,36 @@ int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t work
 int32_t tmp_key_owner(int32_t key, int32_t n_parts);
 
 /* ---------------------------------------------------------------------------------------
+ * Table write layout: the two derived columns and the row order of a date-partitioned,
+ * (key, time)-clustered table.
+ *
+ * Replaces python/tempo/io.py:29-30 (event_dt = to_date(ts); event_time = the "HH:mm:ss[.f]"
+ * part of ts.cast("string") with the colons removed, cast to double), and stands in for
+ * partitionBy("event_dt") + "optimize ... zorder by (partitionCols, ..., event_time)" of
+ * io.py:35-39 with one linear order: rows sorted by (event_dt, key, ts), ties in input order.
+ * Session time zone is UTC.
+ *   out_event_dt[i]   days since 1970-01-01 of input row i (floor for times before the epoch)
+ *   out_event_time[i] HHMMSS.ffffff of input row i as the double nearest to that decimal
+ *   out_perm[p]       input row at position p of the (event_dt, key, ts) order
+ *   out_dt_range      device int32[2]: smallest and largest event_dt (untouched when n == 0)
+ * key may be NULL (no partition columns).  ts is int64 microseconds.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t *out_event_dt;
+  double *out_event_time;
+  int32_t *out_perm;
+  int32_t *out_dt_range;
+} tmp_write_layout_args;
+
+size_t tmp_write_layout_workspace_bytes(const tmp_write_layout_args *a);
+int tmp_write_layout(const tmp_write_layout_args *a, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Diagnostics: per-kernel device time (no counterpart in the reference; Spark exposes stage
  * timings through its UI).  While enabled, every kernel launch of the entry points above is
  * bracketed by two HIP events on its launch stream.  tmp_profile_enable(1) creates the event

@@ -251,3 +251,16 @@ def interpolate(key, ts, freq_us, method, cols, cols_valid):
         assert m >= 0
         return dict(n=int(m), src=src[:m], key=okey[:m], ts=ots[:m], ts_interp=tsi[:m], val=val[:k, :m],
                     valid=valid[:k, :m], interp=interp[:k, :m])
+
+
+def write_layout(key, ts):
+    """(event_dt int32[n], event_time float64[n], perm int64[n]) of python/tempo/io.py:29-39:
+    derived columns in input row order, perm = rows in (event_dt, key, ts) order."""
+    key, ts = _i32(key), _i64(ts)
+    n = len(ts)
+    dt = np.zeros(n, dtype=np.int32)
+    tm = np.zeros(n, dtype=np.float64)
+    perm = np.zeros(n, dtype=np.int64)
+    rc = lib().orc_write_layout(C.c_int64(n), _p(key), _p(ts), _p(dt), _p(tm), _p(perm))
+    assert rc == 0
+    return dt, tm, perm

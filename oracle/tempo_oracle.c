@@ -680,3 +680,53 @@ i64 orc_interpolate(i64 n, const i32 *key, const i64 *ts, i64 freq_us, int metho
   free(perm);
   return total;
 }
+
+/* ------------------------------------------------------------------ table write layout
+ * Follows python/tempo/io.py:29-39.  event_dt = to_date(ts) (UTC session).  event_time: the
+ * reference casts ts to string -- Spark prints "yyyy-MM-dd HH:mm:ss" plus, when the
+ * microseconds are not zero, "." and the six fraction digits with trailing zeros removed --
+ * takes the part after the blank, deletes the colons (translate) and casts the rest to double.
+ * The text is built and parsed here just like that.  The row order is the linear stand-in for
+ * partitionBy("event_dt") + clustering by (partitionCols, event_time): stable sort by
+ * (event_dt, key, ts).
+ */
+#include <stdio.h>
+
+typedef struct {
+  const i32 *dt;
+  const i32 *key;
+  const i64 *ts;
+} wl_ctx;
+
+static int wl_cmp(const void *vctx, i64 a, i64 b) {
+  const wl_ctx *c = (const wl_ctx *)vctx;
+  if (c->dt[a] != c->dt[b]) return c->dt[a] < c->dt[b] ? -1 : 1;
+  if (c->key && c->key[a] != c->key[b]) return c->key[a] < c->key[b] ? -1 : 1;
+  if (c->ts[a] != c->ts[b]) return c->ts[a] < c->ts[b] ? -1 : 1;
+  return 0;
+}
+
+int orc_write_layout(i64 n, const i32 *key, const i64 *ts, i32 *out_dt, double *out_time,
+                     i64 *out_perm) {
+  for (i64 i = 0; i < n; ++i) {
+    i64 day = floordiv64(ts[i], 86400000000ll);
+    i64 tod = ts[i] - day * 86400000000ll;
+    i64 secs = tod / 1000000, micros = tod % 1000000;
+    char text[32], stripped[32];
+    int len = snprintf(text, sizeof(text), "%02d:%02d:%02d", (int)(secs / 3600),
+                       (int)(secs % 3600 / 60), (int)(secs % 60));
+    if (micros) {
+      len += snprintf(text + len, sizeof(text) - (size_t)len, ".%06d", (int)micros);
+      while (text[len - 1] == '0') text[--len] = 0;
+    }
+    int o = 0;
+    for (int k = 0; k < len; ++k)
+      if (text[k] != ':') stripped[o++] = text[k];
+    stripped[o] = 0;
+    out_dt[i] = (i32)day;
+    out_time[i] = strtod(stripped, NULL);
+    out_perm[i] = i;
+  }
+  wl_ctx c = {out_dt, key, ts};
+  return stable_sort_idx(out_perm, n, wl_cmp, &c);
+}

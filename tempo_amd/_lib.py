@@ -95,6 +95,12 @@ class PartitionArgs(C.Structure):
                 ("out_counts", _vp)]
 
 
+class WriteLayoutArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("out_event_dt", _vp), ("out_event_time", _vp), ("out_perm", _vp),
+                ("out_dt_range", _vp)]
+
+
 # every symbol include/tempo_hip.h declares: name -> (restype, argtypes)
 _OP = lambda argt: (C.c_int, [C.POINTER(argt), _vp, C.c_size_t, _vp])
 _WS = lambda argt: (C.c_size_t, [C.POINTER(argt)])
@@ -122,6 +128,8 @@ SYMBOLS = {
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),
+    "tmp_write_layout_workspace_bytes": _WS(WriteLayoutArgs),
+    "tmp_write_layout": _OP(WriteLayoutArgs),
     "tmp_profile_enable": (C.c_int, [C.c_int]),
     "tmp_profile_reset": (C.c_int, []),
     "tmp_profile_count": (C.c_int, []),

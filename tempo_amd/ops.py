@@ -449,3 +449,27 @@ def hash_partition(key, n_parts):
     check(lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
           "tmp_hash_partition")
     return perm, counts
+
+
+def write_layout(key, ts, n_keys):
+    """Derived columns and row order of a date-partitioned, (key, time)-clustered table
+    (python/tempo/io.py:29-39).
+
+    Returns (event_dt int32[n] days since the epoch, event_time float64[n] HHMMSS.ffffff,
+    perm int32[n] = input row at position p of the (event_dt, key, ts) order,
+    dt_range int32[2] = first and last event_dt).  key may be None (no partition columns).
+    """
+    n = ts.numel()
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    dev = ts.device
+    event_dt = torch.empty(n, dtype=torch.int32, device=dev)
+    event_time = torch.empty(n, dtype=torch.float64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    dt_range = torch.zeros(2, dtype=torch.int32, device=dev)
+    a = _lib.WriteLayoutArgs(n, _p(key), int(n_keys), _p(ts), _p(event_dt), _p(event_time), _p(perm),
+                             _p(dt_range))
+    ws = _workspace(lib().tmp_write_layout_workspace_bytes(C.byref(a)), dev)
+    check(lib().tmp_write_layout(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
+          "tmp_write_layout")
+    return event_dt, event_time, perm, dt_range

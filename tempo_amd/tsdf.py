@@ -13,6 +13,7 @@ import pandas as pd
 import torch
 
 from . import columns as col
+from . import io as tio
 from . import ops
 from . import resample as rs
 from .interpol import Interpolation
@@ -261,6 +262,9 @@ class TSDF:
         for name, vals in derived.items():  # tsdf.py:718-719: zscore columns come last
             df[name] = vals
         return TSDF(df, self.ts_col, self.partitionCols)
+
+    def write(self, spark, tabName, optimizationCols=None):  # python/tempo/tsdf.py:761-762
+        tio.write(self, spark, tabName, optimizationCols)
 
     def withGroupedStats(self, metricCols=[], freq=None):
         """mean/count/min/max/sum/stddev of every metric column per partition key and tumbling

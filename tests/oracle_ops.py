@@ -97,3 +97,9 @@ def interpolate(key, ts, n_keys, freq_us, method, cols, cols_valid):
                 val=[_t(np.ascontiguousarray(r["val"][c])) for c in range(k)],
                 valid=[_t(np.ascontiguousarray(r["valid"][c])) for c in range(k)],
                 interp=[_t(np.ascontiguousarray(r["interp"][c])) for c in range(k)])
+
+
+def write_layout(key, ts, n_keys):
+    dt, tm, perm = oracle.write_layout(_np(key), _np(ts))
+    rng = np.array([dt.min(), dt.max()] if len(dt) else [0, 0], dtype=np.int32)
+    return _t(dt), _t(tm), _t(perm, torch.int32), _t(rng)

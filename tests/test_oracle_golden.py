@@ -182,3 +182,22 @@ def test_interpolate_vectors(orc, golden, method):
                 assert r["valid"][c][q] == 1 and r["val"][c][q] == row[3 + c], (q, c)
         assert bool(r["ts_interp"][q]) == row[5]
         assert bool(r["interp"][0][q]) == row[6] and bool(r["interp"][1][q]) == row[7]
+
+
+def test_write_layout_vectors(orc, golden):
+    """io.py:29-39 on the oracle: derived columns of the reference's write test input
+    (tsdf_tests.py:760-766) and the (event_dt, key, ts) order; fractional seconds print with
+    their trailing zeros dropped, as Spark's timestamp-to-string cast does."""
+    fx = golden["write_to_delta"]
+    ts = np.array([ts_us(r[2]) for r in fx["data"]])
+    order = np.array([5, 2, 6, 0, 4, 1, 3])
+    dt, tm, perm = orc.write_layout(np.zeros(7, np.int32), ts[order])
+    assert [str(np.datetime64(int(d), "D")) for d in dt[np.argsort(order)]] == fx["event_dt"]
+    assert tm[np.argsort(order)].tolist() == fx["event_time"]
+    assert order[perm].tolist() == list(range(7))
+    # 23:59:59.5 -> "235959.5"; 00:00:00.000001 -> "000000.000001"; before the epoch dates floor
+    odd = np.array([ts_us("2021-03-04 23:59:59") + 500_000, ts_us("2021-03-04 00:00:00") + 1,
+                    ts_us("1969-12-31 12:30:00") + 250_000])
+    dt, tm, perm = orc.write_layout(None, odd)
+    assert tm.tolist() == [235959.5, 0.000001, 123000.25]
+    assert dt.tolist() == [18690, 18690, -1] and perm.tolist() == [2, 1, 0]
