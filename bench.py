@@ -144,7 +144,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-        from tempo_amd.dist import shuffle_by_key_start
+        from tempo_amd.dist import balanced_owners, shuffle_by_key_start
 
     rows = args.rows
     n_left = n_right = rows // 2
@@ -161,13 +161,23 @@ def main():
         q = tq
         t = tk
         if dist is not None:
-            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  All
+            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  Owners
+            # come from sampled row counts, so that neither the Zipf head of the join keys nor the
+            # short symbol list of the tick table leaves one GPU with far more rows than the rest;
+            # a join key too hot for one GPU is cut into time slices at bracket boundaries of the
+            # skew join (the quotes then carry their bracket tails across slice boundaries).  All
             # three exchanges are issued up front; the tick table's transfers overlap the join.
             _lib.profile_tag(0)
-            p_trades = shuffle_by_key_start(tq["key_l"], [tq["ts_l"], tq["trade_pr"]])
+            own_join = balanced_owners([tq["key_l"], tq["key_r"]], ASOF_KEYS,
+                                       skew=dict(ts_partition_val=10, fraction=0.1),
+                                       ts=[tq["ts_l"], tq["ts_r"]])
+            own_ticks = balanced_owners(tk["key"], TICK_KEYS)
+            p_trades = shuffle_by_key_start(tq["key_l"], [tq["ts_l"], tq["trade_pr"]], owners=own_join,
+                                            ts=tq["ts_l"])
             p_quotes = shuffle_by_key_start(
-                tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]])
-            p_ticks = shuffle_by_key_start(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]])
+                tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]],
+                owners=own_join, ts=tq["ts_r"], halo=True)
+            p_ticks = shuffle_by_key_start(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]], owners=own_ticks)
             kl, (tl, pr), _, _ = p_trades.wait()
             kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
             q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
@@ -274,7 +284,7 @@ def main():
                              "withRangeStats(600 s) on %d ticks per GPU (100 symbols)"
                              % (n_left, n_right, rows)),
                 "rows_per_gpu_per_op": rows,
-                "parallelism": "key-hash shard x%d" % args.gpus,
+                "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
                 "range_stats_device_ms_per_step": round(op_ms.get(2, 0.0) / args.steps, 3),
                 "shuffle_device_ms_per_step": round(op_ms.get(0, 0.0) / args.steps, 3),

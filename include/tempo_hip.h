@@ -422,6 +422,21 @@ int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspace, size_t w
  * that one all-to-all moves every series to the GPU that owns it.
  * out_perm[p] = input row at position p of the bucketed order (stable within a bucket),
  * out_counts[r] (device int64[n_parts]) = rows owned by part r.
+ * owner_table (optional, device int32[n_keys]): owner of every key id, for callers that balance
+ * the parts by row counts (tmp_key_counts) instead of hashing; entries beyond n_parts - 1 are
+ * clamped.  NULL selects the hash.
+ *
+ * Time-sliced keys (skew AS-OF join only, tsdf.py:164-190): a table entry -(s+1) says that key
+ * is too hot for one part and is cut along the time axis.  Its rows go by the index
+ * q = (ts.cast("double") / ts_partition_val).cast("integer") of their time bracket -- the same
+ * expression the join evaluates -- to slice (q - bracket_min) * split_slices[s] / bracket_count
+ * (clamped), owned by slice_owner[split_first[s] + slice].  A left row only ever sees right rows
+ * of its own bracket and the carried-over tail of the bracket before it, so slices are
+ * independent once that tail has been copied across each slice boundary: halo != 0 routes,
+ * instead of the rows, exactly those copies -- rows of sliced keys whose remainder
+ * (ts_double - v*q) / v >= one_minus_fraction and whose next bracket belongs to another part --
+ * to that part.  In halo mode out_counts[r] counts the copies for part r and only the first
+ * sum(out_counts) entries of out_perm are meaningful.  n_parts <= 255 then.
  */
 typedef struct {
   int64_t n;
@@ -429,11 +444,44 @@ typedef struct {
   int32_t n_parts;
   int32_t *out_perm;
   int64_t *out_counts;
+  const int32_t *owner_table;
+  int32_t n_keys; /* length of owner_table; ignored without one */
+  /* everything below is read only when time-sliced keys are in use (ts != NULL) */
+  const int64_t *ts;
+  int32_t ts_is_seconds;
+  int32_t v_is_int;
+  double ts_partition_val;
+  double one_minus_fraction;
+  int64_t bracket_min;
+  int64_t bracket_count;
+  int32_t n_split;
+  const int32_t *split_slices; /* device int32[n_split] */
+  const int32_t *split_first;  /* device int32[n_split] */
+  const int32_t *slice_owner;  /* device int32[sum of split_slices] */
+  int32_t halo;
 } tmp_partition_args;
 
 size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a);
 int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t workspace_bytes,
                        void *stream);
+
+/* Rows per key id over every stride-th row (stride 1 = exact counts): what a balanced owner
+ * table is computed from -- Spark has no counterpart, its hash partitioning leaves a hot key's
+ * task as long as it is (the skew tsdf.py:164-190 works around).  out_counts: device
+ * int64[n_keys], overwritten.  Keys outside [0, n_keys) are rejected by the caller's
+ * dictionary encoding and are skipped here.  Needs no workspace.
+ */
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  int32_t stride;
+  int64_t *out_counts;
+} tmp_key_counts_args;
+
+size_t tmp_key_counts_workspace_bytes(const tmp_key_counts_args *a);
+int tmp_key_counts(const tmp_key_counts_args *a, void *workspace, size_t workspace_bytes,
+                   void *stream);
 /* The owner function itself (host-callable, same arithmetic as the kernel). */
 int32_t tmp_key_owner(int32_t key, int32_t n_parts);
 

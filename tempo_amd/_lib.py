@@ -92,6 +92,15 @@ class InterpolateArgs(C.Structure):
 
 class PartitionArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_parts", C.c_int32), ("out_perm", _vp),
+                ("out_counts", _vp), ("owner_table", _vp), ("n_keys", C.c_int32),
+                ("ts", _vp), ("ts_is_seconds", C.c_int32), ("v_is_int", C.c_int32),
+                ("ts_partition_val", C.c_double), ("one_minus_fraction", C.c_double),
+                ("bracket_min", C.c_int64), ("bracket_count", C.c_int64), ("n_split", C.c_int32),
+                ("split_slices", _vp), ("split_first", _vp), ("slice_owner", _vp), ("halo", C.c_int32)]
+
+
+class KeyCountsArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("stride", C.c_int32),
                 ("out_counts", _vp)]
 
 
@@ -127,6 +136,8 @@ SYMBOLS = {
     "tmp_interpolate": _OP(InterpolateArgs),
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
+    "tmp_key_counts_workspace_bytes": _WS(KeyCountsArgs),
+    "tmp_key_counts": _OP(KeyCountsArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),
     "tmp_write_layout_workspace_bytes": _WS(WriteLayoutArgs),
     "tmp_write_layout": _OP(WriteLayoutArgs),

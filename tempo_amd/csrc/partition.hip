@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "skew.h"
 
 namespace tmp {
 
@@ -17,8 +18,36 @@ __host__ __device__ __forceinline__ uint32_t mix_key(uint32_t k) {
   return k;
 }
 
+// Time-sliced ownership of hot keys (see tmp_partition_args in tempo_hip.h).
+struct SliceArgs {
+  const int64_t *ts;
+  SkewParams sp;
+  int64_t bracket_min;
+  int64_t bracket_count;
+  uint32_t n_split;
+  const int32_t *split_slices;
+  const int32_t *split_first;
+  const int32_t *slice_owner;
+  int halo;
+};
+
+__device__ __forceinline__ uint32_t clamp_owner(int32_t t, uint32_t n_parts) {
+  return t < 0 ? 0u : ((uint32_t)t < n_parts ? (uint32_t)t : n_parts - 1);
+}
+
+__device__ __forceinline__ uint32_t slice_owner_of(const SliceArgs &sl, uint32_t slot, int64_t q,
+                                                    uint32_t n_parts) {
+  const int64_t S = sl.split_slices[slot];
+  int64_t slice = (q - sl.bracket_min) * S / sl.bracket_count;
+  slice = slice < 0 ? 0 : (slice >= S ? S - 1 : slice);
+  return clamp_owner(sl.slice_owner[sl.split_first[slot] + slice], n_parts);
+}
+
+// Owner of every row (the digit of the bucketing pass) and the rows per owner.  In halo mode the
+// digit is the part that needs a COPY of the row, or n_parts ("none") -- counted nowhere.
 __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64_t n, uint32_t n_parts,
-                                                       uint64_t *comp, uint32_t *idx,
+                                                       const int32_t *__restrict__ table, uint32_t n_table,
+                                                       SliceArgs sl, uint64_t *comp, uint32_t *idx,
                                                        unsigned long long *counts) {
   __shared__ unsigned int hist[256];
   for (int i = threadIdx.x; i < 256; i += kBlock) hist[i] = 0;
@@ -33,17 +62,42 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
     const int64_t i = base + lane;
     const bool in = i < n;
     uint32_t o = 0;
+    bool counted = in;
     if (in) {
-      o = mix_key((uint32_t)key[i]) % n_parts;
+      const uint32_t k = (uint32_t)key[i];
+      if (table) {  // balanced ownership: a small table, read by every row (stays in cache)
+        const int32_t t = k < n_table ? table[k] : 0;
+        const bool sliced = t < 0 && sl.ts && (uint32_t)(-(t + 1)) < sl.n_split;
+        if (sliced) {
+          const uint32_t slot = (uint32_t)(-(t + 1));
+          const int64_t ts = sl.ts[i];
+          const int32_t q = bracket_index(ts, sl.sp);
+          o = slice_owner_of(sl, slot, q, n_parts);
+          if (sl.halo) {
+            // the carried-over tail of bracket q is read by bracket q + 1
+            const double d = bracket_seconds(ts, sl.sp);
+            const double part = bracket_part(d, sl.sp);
+            const bool tail = (d - part) / sl.sp.v >= sl.sp.one_minus_fraction;
+            const uint32_t o2 = slice_owner_of(sl, slot, (int64_t)q + 1, n_parts);
+            counted = tail && o2 != o;
+            o = counted ? o2 : n_parts;
+          }
+        } else {
+          o = clamp_owner(t, n_parts);
+          if (sl.halo) { counted = false; o = n_parts; }
+        }
+      } else {
+        o = mix_key(k) % n_parts;
+      }
       comp[i] = o;
       idx[i] = (uint32_t)i;
     }
     if (few) {
       for (uint32_t p = 0; p < n_parts; ++p) {
-        uint64_t b = __ballot(in && o == p);
+        uint64_t b = __ballot(counted && o == p);
         if ((uint32_t)lane == p) mine += (unsigned int)__popcll(b);
       }
-    } else if (in) {
+    } else if (counted) {
       atomicAdd(&hist[o], 1u);
     }
   }
@@ -51,6 +105,34 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
   __syncthreads();
   for (int i = threadIdx.x; i < (int)n_parts; i += kBlock)
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+// Rows per key over every stride-th row.  Small dictionaries are counted in LDS per block and
+// flushed once; a counter is touched through an atomic only by the lanes that hold the key, and
+// the flush skips empty counters.
+constexpr int kCountLds = 12288;
+
+__global__ __launch_bounds__(kBlock) void key_counts_kernel(const int32_t *__restrict__ key, int64_t n_samples,
+                                                            int64_t stride, uint32_t n_keys,
+                                                            unsigned long long *counts) {
+  __shared__ unsigned int hist[kCountLds];
+  const bool local = n_keys <= (uint32_t)kCountLds;
+  if (local) {
+    for (uint32_t i = threadIdx.x; i < n_keys; i += kBlock) hist[i] = 0;
+    __syncthreads();
+  }
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_samples; s += step) {
+    const uint32_t k = (uint32_t)key[s * stride];
+    if (k >= n_keys) continue;
+    if (local) atomicAdd(&hist[k], 1u);
+    else atomicAdd(&counts[k], 1ull);
+  }
+  if (local) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_keys; i += kBlock)
+      if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+  }
 }
 
 __global__ void copy_u32_i32_kernel(const uint32_t *in, int32_t *out, int64_t n) {
@@ -91,12 +173,60 @@ extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
   OrderBuffers b;
   order_plan(a->n, ws, &b);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_hash_partition: workspace too small");
+  TMP_REQUIRE(!a->owner_table || a->n_keys >= 1, TMP_EINVAL,
+              "tmp_hash_partition: owner_table needs n_keys >= 1");
+  SliceArgs sl;
+  memset(&sl, 0, sizeof(sl));
+  if (a->owner_table && a->ts) {
+    TMP_REQUIRE(a->n_split >= 0 && (a->n_split == 0 || (a->split_slices && a->split_first && a->slice_owner)),
+                TMP_EINVAL, "tmp_hash_partition: sliced keys need split_slices, split_first and slice_owner");
+    TMP_REQUIRE(a->ts_partition_val > 0 && a->bracket_count >= 1, TMP_EINVAL,
+                "tmp_hash_partition: sliced keys need ts_partition_val > 0 and bracket_count >= 1");
+    TMP_REQUIRE(!a->halo || a->n_parts <= 255, TMP_EINVAL, "tmp_hash_partition: halo mode takes at most 255 parts");
+    sl.ts = a->ts;
+    sl.sp.enabled = 1;
+    sl.sp.v_is_int = a->v_is_int;
+    sl.sp.ts_is_seconds = a->ts_is_seconds;
+    sl.sp.v = a->ts_partition_val;
+    sl.sp.one_minus_fraction = a->one_minus_fraction;
+    sl.bracket_min = a->bracket_min;
+    sl.bracket_count = a->bracket_count;
+    sl.n_split = (uint32_t)a->n_split;
+    sl.split_slices = a->split_slices;
+    sl.split_first = a->split_first;
+    sl.slice_owner = a->slice_owner;
+    sl.halo = a->halo != 0;
+  } else {
+    TMP_REQUIRE(!a->halo, TMP_EINVAL, "tmp_hash_partition: halo mode needs an owner table and ts");
+  }
   TMP_LAUNCH(owner_kernel, dim3(grid_for(a->n, kBlock * 8, 2048)), dim3(kBlock), st, a->key, a->n,
-             (uint32_t)a->n_parts, b.comp[0], b.idx[0], (unsigned long long *)a->out_counts);
+             (uint32_t)a->n_parts, a->owner_table, (uint32_t)(a->owner_table ? a->n_keys : 0), sl,
+             b.comp[0], b.idx[0], (unsigned long long *)a->out_counts);
   OrderResult res;
-  TMP_TRY(order_radix_passes(b, a->n, 0, bits_for((uint64_t)a->n_parts - 1), &res, st));
+  // halo mode buckets into n_parts + 1 digits, the last one being "no copy"
+  TMP_TRY(order_radix_passes(b, a->n, 0, bits_for((uint64_t)a->n_parts - (sl.halo ? 0 : 1)), &res, st));
   TMP_LAUNCH(copy_u32_i32_kernel, dim3(grid_for(a->n, kBlock * 4, 8192)), dim3(kBlock), st, res.perm,
              a->out_perm, a->n);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
+
+extern "C" size_t tmp_key_counts_workspace_bytes(const tmp_key_counts_args *) { return 0; }
+
+extern "C" int tmp_key_counts(const tmp_key_counts_args *a, void *, size_t, void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_key_counts: null args");
+  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31), TMP_EINVAL, "tmp_key_counts: bad row count");
+  TMP_REQUIRE(a->n_keys >= 1 && a->out_counts, TMP_EINVAL, "tmp_key_counts: n_keys >= 1 and out_counts needed");
+  TMP_REQUIRE(a->stride >= 1, TMP_EINVAL, "tmp_key_counts: stride must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  TMP_CHECK_HIP(hipMemsetAsync(a->out_counts, 0, sizeof(int64_t) * (size_t)a->n_keys, st));
+  if (a->n == 0) return TMP_OK;
+  TMP_REQUIRE(a->key, TMP_EINVAL, "tmp_key_counts: null key column");
+  const int64_t n_samples = (a->n + a->stride - 1) / a->stride;
+  // few blocks when the counters live in LDS: each one flushes up to n_keys counters
+  TMP_LAUNCH(key_counts_kernel, dim3(grid_for(n_samples, kBlock * 64, 1024)), dim3(kBlock), st, a->key,
+             n_samples, (int64_t)a->stride, (uint32_t)a->n_keys, (unsigned long long *)a->out_counts);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

@@ -2,10 +2,14 @@
 
 Spark's Exchange hashpartitioning(partitionCols) in front of every Window / groupBy
 (python/tempo/tsdf.py:121, :571; python/tempo/resample.py:63) becomes one all-to-all per
-column: rows are bucketed on the device by owner = mix(key) % world_size
-(tmp_hash_partition), exchanged with all_to_all, and every later operator runs locally on the
-series a rank owns -- no other collective is on the data path.
+column: rows are bucketed on the device by owner(key) (tmp_hash_partition), exchanged with
+all_to_all, and every later operator runs locally on the series a rank owns -- no other
+collective is on the data path.  owner(key) is mix(key) % world_size, or -- balanced_owners --
+a table that spreads the keys by their row counts, so that a hot key (the skew
+python/tempo/tsdf.py:164-190 works around) or a short key list does not leave one GPU with
+far more rows than the others.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -16,12 +20,148 @@ from . import ops
 MAX_MESSAGE_BYTES = 1 << 30
 
 
-def _hip_partition(key, n_parts):
-    return ops.hash_partition(key, n_parts)
+def _hip_partition(key, n_parts, table=None, slices=None, ts=None, halo=False):
+    return ops.hash_partition(key, n_parts, table, slices, ts, halo)
 
 
 def _hip_take(col, perm):
     return ops.gather(col, perm, want_valid=False)[0]
+
+
+def _hip_counts(key, n_keys, stride):
+    return ops.key_counts(key, n_keys, stride)
+
+
+def assign_owners(counts, world):
+    """Owner per key id from global row counts (host, deterministic: every rank computes the same
+    table from the same counts).  Keys are taken in order of decreasing count and each goes to
+    the rank with the fewest rows so far (longest-processing-time rule); keys nobody sampled are
+    dealt out round-robin.  A key is never split: one that holds more than 1/world of the rows
+    still overloads its owner."""
+    counts = np.asarray(counts, dtype=np.int64)
+    owners = np.empty(len(counts), dtype=np.int32)
+    order = np.argsort(-counts, kind="stable")
+    seen = order[counts[order] > 0]
+    load = np.zeros(world, dtype=np.int64)
+    # the heavy head one by one; the long tail of small keys a round at a time, onto the ranks
+    # that are still below their fair share (lightest rank first)
+    head = min(len(seen), 64 * world)
+    for k in seen[:head]:
+        r = int(np.argmin(load))
+        owners[k] = r
+        load[r] += counts[k]
+    rest = seen[head:]
+    fair = (int(counts.sum()) + world - 1) // world
+    lo = 0
+    while lo < len(rest):
+        ranks = np.argsort(load, kind="stable")
+        below = ranks[load[ranks] < fair]
+        ranks = below if len(below) else ranks[:1]
+        # decreasing counts dealt over increasing loads, 64 rounds per look at the loads (these
+        # keys are small next to a rank's share)
+        chunk = rest[lo:lo + 64 * len(ranks)]
+        to = ranks[np.arange(len(chunk)) % len(ranks)]
+        owners[chunk] = to
+        load += np.bincount(to, weights=counts[chunk], minlength=world).astype(np.int64)
+        lo += len(chunk)
+    unseen = order[counts[order] <= 0]
+    owners[unseen] = np.arange(len(unseen), dtype=np.int32) % world
+    return owners
+
+
+class OwnerPlan:
+    """Who owns which key: `table` (int32[n_keys] on the device) and, when hot keys are cut along
+    the time axis, `slices` (the dict ops.hash_partition takes)."""
+
+    def __init__(self, table, slices=None):
+        self.table, self.slices = table, slices
+
+
+def _bracket_index(ts, v, ts_is_seconds):
+    """(ts.cast("double") / v).cast("integer") of python/tempo/tsdf.py:178-179 on the host, the
+    same IEEE operations as the device (truncation, saturating)."""
+    d = np.float64(ts) if ts_is_seconds else np.float64(ts) / np.float64(1000000.0)
+    q = np.trunc(d / np.float64(v))
+    return int(min(max(q, -2147483648.0), 2147483647.0))
+
+
+def balanced_owners(keys, n_keys, group=None, stride=16, counts_fn=None, skew=None, ts=None):
+    """OwnerPlan that balances the rows of `keys` -- one or more key columns sharing a
+    dictionary, e.g. both sides of a join -- over the ranks.  Counts every stride-th row on the
+    device, sums the counts over ranks (one small all-reduce) and assigns keys on the host;
+    every rank ends up with the same plan.
+
+    skew=dict(ts_partition_val=, fraction=, ts_is_seconds=) with ts (the time columns that go
+    with `keys`) allows a key with more than half a rank's fair share of the rows to be cut
+    into time slices owned by different ranks.  That is exact for the skew AS-OF join only
+    (python/tempo/tsdf.py:164-190: a left row sees its own time bracket and the tail of the one
+    before), and the right side must then be shuffled with halo=True."""
+    counts_fn = counts_fn or _hip_counts
+    if isinstance(keys, torch.Tensor):
+        keys = [keys]
+    world = dist.get_world_size(group)
+    total = None
+    for k in keys:
+        c = counts_fn(k, n_keys, stride)
+        total = c if total is None else total + c
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    counts = total.cpu().numpy().astype(np.int64)
+    dev = keys[0].device
+    ts_range = None
+    if skew is not None and world > 1 and len(hot_keys(counts, world)):
+        if isinstance(ts, torch.Tensor):
+            ts = [ts]
+        big = torch.iinfo(torch.int64).max
+        lo = min([int(t.min()) for t in ts if t.numel()] or [big])
+        hi = max([int(t.max()) for t in ts if t.numel()] or [-big])
+        ends = torch.tensor([lo, -hi], dtype=torch.int64, device=dev)
+        dist.all_reduce(ends, op=dist.ReduceOp.MIN, group=group)
+        ts_range = (int(ends[0]), -int(ends[1]))
+    return plan_owners(counts, world, dev, skew, ts_range)
+
+
+def hot_keys(counts, world):
+    """Keys holding more than half of a rank's fair share of the rows."""
+    fair = max(1, int(counts.sum()) // world)
+    return np.flatnonzero(counts > fair // 2)
+
+
+def plan_owners(counts, world, device, skew=None, ts_range=None):
+    """OwnerPlan from global per-key row counts (host arithmetic only; same inputs, same plan).
+    With skew and the global (min, max) of the time columns, hot keys are cut into time slices."""
+    counts = np.asarray(counts, dtype=np.int64)
+    n_keys = len(counts)
+    hot = hot_keys(counts, world) if (skew is not None and ts_range is not None and world > 1) else np.arange(0)
+    if len(hot):
+        v = skew["ts_partition_val"]
+        v_is_int = isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+        secs = bool(skew.get("ts_is_seconds", False))
+        lo, hi = ts_range
+        q_lo, q_hi = _bracket_index(lo, v, secs), _bracket_index(hi, v, secs)
+        # slices are cut by bracket index; that is only the join's own cut while v * q neither
+        # saturates nor wraps
+        usable = (lo <= hi and -2147483648 < q_lo and q_hi < 2147483647 and q_hi > q_lo
+                  and (not v_is_int or max(abs(q_lo), abs(q_hi) + 1) * abs(int(v)) < 2 ** 31))
+        if usable:
+            fair = max(1, int(counts.sum()) // world)
+            n_brackets = q_hi - q_lo + 1
+            per_slice = max(1, fair // 8)
+            n_slices = np.minimum(np.minimum(-(-counts[hot] // per_slice), 256), n_brackets).astype(np.int64)
+            items = counts.copy()
+            items[hot] = 0
+            items = np.concatenate([items] + [np.full(int(S), int(c // S), dtype=np.int64)
+                                              for c, S in zip(counts[hot], n_slices)])
+            owners = assign_owners(items, world)
+            table = owners[:n_keys].copy()
+            table[hot] = -(np.arange(len(hot), dtype=np.int32) + 1)
+            first = np.concatenate([[0], np.cumsum(n_slices)[:-1]]).astype(np.int32)
+            slices = dict(ts_partition_val=float(v), v_is_int=v_is_int, ts_is_seconds=secs,
+                          one_minus_fraction=1 - skew["fraction"], bracket_min=q_lo, bracket_count=n_brackets,
+                          split_slices=torch.from_numpy(n_slices.astype(np.int32)).to(device),
+                          split_first=torch.from_numpy(first).to(device),
+                          slice_owner=torch.from_numpy(owners[n_keys:].astype(np.int32)).to(device))
+            return OwnerPlan(torch.from_numpy(table).to(device), slices)
+    return OwnerPlan(torch.from_numpy(assign_owners(counts, world)).to(device))
 
 
 def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
@@ -64,7 +204,8 @@ class PendingShuffle:
         return self._received[0], self._received[1:], self.send_counts, self.recv_counts
 
 
-def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=None):
+def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=None, owners=None,
+                         ts=None, halo=False):
     """Start sending every row to the rank that owns its key; returns a PendingShuffle.
 
     The device bucketing and the count exchange happen here (one small blocking read); the
@@ -72,35 +213,59 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     this call and overlaps with the transfers.
     key: int32 tensor of GLOBAL dictionary ids (the same id for the same key on every rank).
     columns: list of 1-D tensors with one entry per row (1-, 4- or 8-byte element types).
+    owners: optional OwnerPlan from balanced_owners (the same one for every table that has to
+    be co-located, such as the two sides of a join); default is the hash.  A plan with time
+    slices needs `ts` (the table's time column, which still has to be listed in `columns` to
+    travel), and halo=True for the right side of the join: rows in the carried-over tail of a
+    bracket at a slice boundary are then sent to the next slice's owner as well, and arrive
+    after the rank's own rows.
     partition_fn / take_fn default to the HIP kernels; tests on CPU inject host equivalents.
     """
     world = dist.get_world_size(group)
     partition_fn = partition_fn or _hip_partition
     take_fn = take_fn or _hip_take
-    perm, counts = partition_fn(key, world)
-    send = counts.to(torch.int64)
+    sliced = owners is not None and owners.slices is not None
+    if sliced and ts is None:
+        raise ValueError("an owner plan with time slices needs the table's ts column")
+    if owners is None:
+        perm, counts = partition_fn(key, world)
+    elif sliced:
+        perm, counts = partition_fn(key, world, owners.table, owners.slices, ts)
+    else:
+        perm, counts = partition_fn(key, world, owners.table)
+    parts = [(perm, counts)]
+    if sliced and halo:
+        parts.append(partition_fn(key, world, owners.table, owners.slices, ts, True))
+    send = torch.stack([c.to(torch.int64) for _, c in parts])          # [1 or 2][world]
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
+    for i in range(len(parts)):
+        dist.all_to_all_single(recv[i], send[i], group=group)
     # every rank must run the same number of rounds: size them by the largest pairwise message
-    biggest = torch.maximum(send.max(), recv.max()).reshape(1)
+    biggest = torch.maximum(send.max(dim=1).values, recv.max(dim=1).values)
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
-    send_l = [int(v) for v in send.cpu().tolist()]
-    recv_l = [int(v) for v in recv.cpu().tolist()]
-    biggest = int(biggest.item())
-    n_recv = sum(recv_l)
+    send_l, recv_l, biggest = send.cpu().tolist(), recv.cpu().tolist(), biggest.cpu().tolist()
+    n_recv = [sum(r) for r in recv_l]
     works, staged_all, out_cols = [], [], []
     for col in [key] + list(columns):
-        staged = take_fn(col, perm)
-        got = torch.empty(n_recv, dtype=col.dtype, device=col.device)
+        got = torch.empty(sum(n_recv), dtype=col.dtype, device=col.device)
         rows_per_round = max(1, MAX_MESSAGE_BYTES // col.element_size())
-        rounds = max(1, -(-biggest // rows_per_round))
-        works += _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group)
-        staged_all.append(staged)
+        at = 0
+        for i, (p, _) in enumerate(parts):
+            if int(biggest[i]) == 0:  # nothing to move anywhere (all ranks agree on that)
+                continue
+            staged = take_fn(col, p if i == 0 else p[:sum(send_l[i])])
+            rounds = max(1, -(-int(biggest[i]) // rows_per_round))
+            works += _exchange(staged, got[at:at + n_recv[i]], send_l[i], recv_l[i], rounds, rows_per_round, group)
+            staged_all.append(staged)
+            at += n_recv[i]
         out_cols.append(got)
-    return PendingShuffle(works, staged_all, out_cols, send_l, recv_l)
+    total_send = [sum(v) for v in zip(*send_l)]
+    total_recv = [sum(v) for v in zip(*recv_l)]
+    return PendingShuffle(works, staged_all, out_cols, total_send, total_recv)
 
 
-def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None):
+def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None, owners=None, ts=None,
+                   halo=False):
     """Send every row to the rank that owns its key (blocking form of shuffle_by_key_start).
     Returns (key_local, columns_local, send_counts, recv_counts)."""
-    return shuffle_by_key_start(key, columns, group, partition_fn, take_fn).wait()
+    return shuffle_by_key_start(key, columns, group, partition_fn, take_fn, owners, ts, halo).wait()

@@ -438,17 +438,48 @@ def interpolate(key, ts, n_keys, freq_us, method, cols, cols_valid):
                 valid=[valid[c, :m] for c in range(k)], interp=[interp[c, :m] for c in range(k)])
 
 
-def hash_partition(key, n_parts):
-    """Bucket rows by owner = hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts])."""
+def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=False):
+    """Bucket rows by owner: owner_table[key] when a table (int32[n_keys], device) is given, else
+    hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts]).
+
+    slices (with ts): time-sliced ownership of hot keys for the skew AS-OF join -- a dict with
+    ts_partition_val, v_is_int, one_minus_fraction, ts_is_seconds, bracket_min, bracket_count and
+    the device int32 tensors split_slices, split_first, slice_owner (include/tempo_hip.h,
+    tmp_partition_args).  halo=True routes the copies of carried-over rows instead of the rows;
+    only the first counts.sum() entries of perm are meaningful then."""
     n = key.numel()
     _dev(key, torch.int32, "key")
+    _dev(owner_table, torch.int32, "owner_table")
     perm = torch.empty(n, dtype=torch.int32, device=key.device)
     counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
-    a = PartitionArgs(n, _p(key), int(n_parts), _p(perm), _p(counts))
+    a = PartitionArgs(n, _p(key), int(n_parts), _p(perm), _p(counts), _p(owner_table),
+                      0 if owner_table is None else owner_table.numel())
+    if slices is not None:
+        _dev(ts, torch.int64, "ts", n)
+        for name in ("split_slices", "split_first", "slice_owner"):
+            _dev(slices[name], torch.int32, name)
+        a.ts, a.ts_is_seconds, a.v_is_int = _p(ts), int(bool(slices["ts_is_seconds"])), int(bool(slices["v_is_int"]))
+        a.ts_partition_val, a.one_minus_fraction = float(slices["ts_partition_val"]), float(slices["one_minus_fraction"])
+        a.bracket_min, a.bracket_count = int(slices["bracket_min"]), int(slices["bracket_count"])
+        a.n_split = slices["split_slices"].numel()
+        a.split_slices, a.split_first, a.slice_owner = (_p(slices["split_slices"]), _p(slices["split_first"]),
+                                                        _p(slices["slice_owner"]))
+        a.halo = int(bool(halo))
+    elif halo:
+        raise ValueError("halo routing needs sliced keys")
     ws = _workspace(lib().tmp_hash_partition_workspace_bytes(C.byref(a)), key.device)
     check(lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
           "tmp_hash_partition")
     return perm, counts
+
+
+def key_counts(key, n_keys, stride=1):
+    """Rows per key id over every stride-th row: int64[n_keys] on the device."""
+    _dev(key, torch.int32, "key")
+    counts = torch.empty(int(n_keys), dtype=torch.int64, device=key.device)
+    a = _lib.KeyCountsArgs(key.numel(), _p(key), int(n_keys), int(stride), _p(counts))
+    check(lib().tmp_key_counts(C.byref(a), None, 0, _stream()), "tmp_key_counts")
+    return counts
 
 
 def write_layout(key, ts, n_keys):

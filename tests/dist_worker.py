@@ -17,14 +17,44 @@ from tempo_amd import _lib  # noqa: E402
 from tempo_amd.dist import shuffle_by_key  # noqa: E402
 
 
-def host_partition(key, n_parts):
-    owner = np.array([_lib.lib().tmp_key_owner(int(k), n_parts) for k in key.numpy()], dtype=np.int64)
-    perm = np.argsort(owner, kind="stable")
-    return torch.from_numpy(perm.astype(np.int32)), torch.from_numpy(np.bincount(owner, minlength=n_parts))
+from host_partition import host_counts, host_partition, host_take  # noqa: E402
 
 
-def host_take(col, perm):
-    return col[perm.to(torch.int64)]
+def join_tables():
+    """Global trades / quotes of the sliced-key scenario: key 0 holds ~70 % of the rows."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    base = 1_596_240_000_000_000
+    hot = lambda: np.where(rng.random(n) < 0.7, 0, rng.integers(1, 6, n)).astype(np.int32)
+    kl, kr = hot(), hot()
+    tl = base + rng.integers(0, 600_000, n) * 1000
+    tr = base + rng.integers(0, 600_000, n) * 1000
+    va = (rng.random(n) > 0.2).astype(np.uint8)
+    return kl, tl, kr, tr, va
+
+
+def join_scenario(out_dir, rank, world):
+    from tempo_amd.dist import balanced_owners
+    kl, tl, kr, tr, va = join_tables()
+    n = len(kl)
+    sl = slice(rank * n // world, (rank + 1) * n // world)
+    T = torch.from_numpy
+    rid = np.arange(n, dtype=np.int64)
+    skew = dict(ts_partition_val=10, fraction=0.1, ts_is_seconds=False)
+    plan = balanced_owners([T(kl[sl]), T(kr[sl])], 6, stride=1, counts_fn=host_counts, skew=skew,
+                           ts=[T(tl[sl]), T(tr[sl])])
+    assert plan.slices is not None and int(plan.table[0]) == -1, "the hot key was not sliced"
+    k1, (t1, r1), _, _ = shuffle_by_key(T(kl[sl]), [T(tl[sl]), T(rid[sl])], partition_fn=host_partition,
+                                        take_fn=host_take, owners=plan, ts=T(tl[sl]))
+    k2, (t2, v2, r2), _, _ = shuffle_by_key(T(kr[sl]), [T(tr[sl]), T(va[sl]), T(rid[sl])],
+                                            partition_fn=host_partition, take_fn=host_take, owners=plan,
+                                            ts=T(tr[sl]), halo=True)
+    assert (k1 == 0).any(), "every rank should own a slice of the hot key"
+    idx, _ = oracle.asof_join(k1.numpy(), t1.numpy(), k2.numpy(), t2.numpy(), valid_r=[None, v2.numpy()],
+                              ts_partition_val=10, fraction=0.1)
+    r2n = r2.numpy()
+    np.savez(os.path.join(out_dir, f"join{rank}.npz"), left=r1.numpy(),
+             right=np.where(idx >= 0, r2n[np.maximum(idx, 0)], -1))
 
 
 def main():
@@ -48,6 +78,7 @@ def main():
     r = oracle.range_stats(k_loc.numpy(), ts_loc.numpy(), x_loc.numpy(), None, 30)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rid=rid_loc.numpy()[r["perm"]], mean=r["mean"],
              count=r["count"], stddev=r["stddev"], mx=r["max"])
+    join_scenario(out_dir, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

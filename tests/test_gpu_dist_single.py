@@ -54,3 +54,136 @@ def test_hash_partition_many_parts(orc):
         assert np.array_equal(perm.cpu().numpy(), np.argsort(owner, kind="stable"))
         # shares are balanced to a few percent for 10k keys
         assert counts.max().item() < 1.2 * n / parts
+
+
+def test_key_counts(orc):
+    from tempo_amd import ops
+    rng = np.random.default_rng(2)
+    for n, n_keys, stride in [(250_000, 100, 1), (250_001, 10_000, 16), (70_000, 50_000, 3), (5, 7, 1), (0, 4, 1)]:
+        key = rng.integers(0, n_keys, n).astype(np.int32)
+        key[: n // 3] = 0  # a hot key
+        got = ops.key_counts(torch.from_numpy(key).cuda(), n_keys, stride).cpu().numpy()
+        assert np.array_equal(got, np.bincount(key[::stride], minlength=n_keys))
+
+
+def _skew_tables(rng, n, n_keys, hot_share):
+    base = 1_596_240_000_000_000
+    mk = lambda: np.where(rng.random(n) < hot_share, 0, rng.integers(1, n_keys, n)).astype(np.int32)
+    kl, kr = mk(), mk()
+    tl = base + rng.integers(0, 3_600_000, n) * 1000
+    tr = base + rng.integers(0, 3_600_000, n) * 1000
+    return kl, tl, kr, tr
+
+
+@pytest.mark.parametrize("v", [10, 2.5])
+def test_partition_with_owner_table_and_time_slices(orc, v):
+    """Device routing == the host statement of the rules, for plain tables, sliced keys and the
+    halo copies, at 8 parts."""
+    from host_partition import host_partition
+    from tempo_amd import ops
+    from tempo_amd.dist import plan_owners
+    rng = np.random.default_rng(5)
+    n, n_keys, world = 400_000, 300, 8
+    kl, tl, kr, tr = _skew_tables(rng, n, n_keys, 0.3)
+    counts = np.bincount(kl, minlength=n_keys) + np.bincount(kr, minlength=n_keys)
+    dev = torch.device("cuda")
+    plain = plan_owners(counts, world, dev)
+    perm, cnt = ops.hash_partition(torch.from_numpy(kl).cuda(), world, plain.table)
+    e_perm, e_cnt = host_partition(kl, world, plain.table)
+    assert np.array_equal(perm.cpu().numpy(), e_perm.numpy()) and np.array_equal(cnt.cpu().numpy(), e_cnt.numpy())
+    assert cnt.max().item() > 1.5 * n / world          # the hot key overloads its owner ...
+    plan = plan_owners(counts, world, dev, skew=dict(ts_partition_val=v, fraction=0.1),
+                       ts_range=(int(min(tl.min(), tr.min())), int(max(tl.max(), tr.max()))))
+    assert plan.slices is not None
+    for key, ts, halo in [(kl, tl, False), (kr, tr, False), (kr, tr, True)]:
+        perm, cnt = ops.hash_partition(torch.from_numpy(key).cuda(), world, plan.table, plan.slices,
+                                       torch.from_numpy(ts).cuda(), halo)
+        e_perm, e_cnt = host_partition(key, world, plan.table, plan.slices, ts, halo)
+        assert np.array_equal(cnt.cpu().numpy(), e_cnt.numpy())
+        m = int(e_cnt.sum())
+        assert np.array_equal(perm.cpu().numpy()[:m], e_perm.numpy()[:m])
+        if not halo:
+            assert cnt.max().item() < 1.1 * n / world   # ... unless it is cut along the time axis
+        else:
+            assert 0 < m < n // 20
+
+
+def test_sliced_join_equals_whole_join(orc):
+    """Eight simulated ranks on one GPU: route both sides (and the halo copies) with the device
+    kernels, join every part on its own, and the union must be the single join row for row."""
+    from tempo_amd import ops
+    from tempo_amd.dist import plan_owners
+    rng = np.random.default_rng(6)
+    n, n_keys, world = 300_000, 50, 8
+    kl, tl, kr, tr = _skew_tables(rng, n, n_keys, 0.4)
+    bid = rng.normal(100, 1, n)
+    bv = (rng.random(n) > 0.05).astype(np.uint8)
+    pr = rng.normal(100, 1, n)
+    d = lambda a: torch.from_numpy(a).cuda()
+    counts = np.bincount(kl, minlength=n_keys) + np.bincount(kr, minlength=n_keys)
+    plan = plan_owners(counts, world, torch.device("cuda"), skew=dict(ts_partition_val=10, fraction=0.1),
+                       ts_range=(int(min(tl.min(), tr.min())), int(max(tl.max(), tr.max()))))
+    assert plan.slices is not None
+
+    def join(kl_, tl_, pr_, kr_, tr_, bid_, bv_):
+        j = ops.asof_join_table(kl_, tl_, kr_, tr_, n_keys, [pr_], [tr_, bid_], [None, bv_], skip_nulls=True,
+                                ts_partition_val=10, fraction=0.1)
+        torch.cuda.synchronize()
+        rts, rts_ok = j["right"][0]
+        rb, rb_ok = j["right"][1]
+        rows = np.stack([j["key"].cpu().numpy().astype(np.float64), j["ts"].cpu().numpy().astype(np.float64),
+                         j["left"][0].cpu().numpy(),
+                         np.where(rts_ok.cpu().numpy() != 0, rts.cpu().numpy().astype(np.float64), -1.0),
+                         np.where(rb_ok.cpu().numpy() != 0, rb.cpu().numpy(), -1.0)], axis=1)
+        return rows
+
+    whole = join(d(kl), d(tl), d(pr), d(kr), d(tr), d(bid), d(bv))
+    pl, cl = ops.hash_partition(d(kl), world, plan.table, plan.slices, d(tl))
+    pr_, cr = ops.hash_partition(d(kr), world, plan.table, plan.slices, d(tr))
+    ph, ch = ops.hash_partition(d(kr), world, plan.table, plan.slices, d(tr), True)
+    pl, pr_, ph = pl.cpu().numpy(), pr_.cpu().numpy(), ph.cpu().numpy()
+    ol = np.r_[0, np.cumsum(cl.cpu().numpy())]
+    orr = np.r_[0, np.cumsum(cr.cpu().numpy())]
+    oh = np.r_[0, np.cumsum(ch.cpu().numpy())]
+    assert oh[-1] > 0
+    parts = []
+    for r in range(world):
+        li = pl[ol[r]:ol[r + 1]]
+        ri = np.r_[pr_[orr[r]:orr[r + 1]], ph[oh[r]:oh[r + 1]]]
+        if len(li) == 0:
+            continue
+        parts.append(join(d(kl[li]), d(tl[li]), d(pr[li]), d(kr[ri]), d(tr[ri]), d(bid[ri]), d(bv[ri])))
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape
+    order = lambda a: a[np.lexsort(a.T[::-1])]
+    assert np.array_equal(order(got), order(whole))
+
+
+def test_shuffle_with_sliced_plan_single_rank_nccl():
+    """The device shuffle with a time-sliced owner plan and halo routing on a one-rank RCCL
+    group: every slice has the same owner, so nothing is copied and every row arrives once."""
+    import torch.distributed as dist
+    from tempo_amd.dist import OwnerPlan, shuffle_by_key
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(8)
+        kl, tl, kr, tr = _skew_tables(rng, 100_000, 20, 0.5)
+        d = lambda a: torch.from_numpy(a).cuda()
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+        table = torch.zeros(20, dtype=torch.int32, device="cuda")
+        table[0] = -1
+        plan = OwnerPlan(table, dict(ts_partition_val=10.0, v_is_int=True, ts_is_seconds=False,
+                                     one_minus_fraction=0.9, bracket_min=int(tr.min() // 10_000_000),
+                                     bracket_count=361, split_slices=i32([4]), split_first=i32([0]),
+                                     slice_owner=i32([0, 0, 0, 0])))
+        k2, (t2,), send, recv = shuffle_by_key(d(kr), [d(tr)], owners=plan, ts=d(tr), halo=True)
+        assert send == [len(kr)] and recv == [len(kr)]
+        assert np.array_equal(k2.cpu().numpy(), kr) and np.array_equal(t2.cpu().numpy(), tr)
+    finally:
+        if created:
+            dist.destroy_process_group()
