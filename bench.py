@@ -122,6 +122,12 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: native libraries that print banners to file
+    # descriptor 1 (RCCL does when it starts) are pointed at stderr until that line goes out
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,6 +290,7 @@ def main():
                              "withRangeStats(600 s) on %d ticks per GPU (100 symbols)"
                              % (n_left, n_right, rows)),
                 "rows_per_gpu_per_op": rows,
+                "peak_hbm_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
                 "range_stats_device_ms_per_step": round(op_ms.get(2, 0.0) / args.steps, 3),
@@ -293,7 +300,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if dist:
         dist.destroy_process_group()
 

@@ -465,6 +465,29 @@ size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a);
 int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* Route and move in one call: what tmp_hash_partition + one tmp_gather per column deliver, without
+ * row ids or sort passes, for up to 64 parts.  `route` is read like tmp_hash_partition's
+ * argument (out_perm is not used); afterwards out_cols[c][first(r) + j] = cols[c][i_j], i_j the
+ * j-th input row routed to part r in input order, first(r) = route.out_counts[0] + ... +
+ * route.out_counts[r-1].  Element sizes 1, 4 and 8 bytes; cols / col_bytes / out_cols are HOST
+ * arrays of n_cols entries (at most 12).  capacity = rows every output column has room for:
+ * route.n always suffices; in halo mode few rows move and a smaller capacity may be offered --
+ * TMP_ECAPACITY (with route.out_counts valid) says it was not enough.  Does one small
+ * device->host read.
+ */
+typedef struct {
+  tmp_partition_args route;
+  int32_t n_cols;
+  const void *const *cols;
+  const int32_t *col_bytes;
+  void *const *out_cols;
+  int64_t capacity;
+} tmp_partition_move_args;
+
+size_t tmp_partition_move_workspace_bytes(const tmp_partition_move_args *a);
+int tmp_partition_move(const tmp_partition_move_args *a, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 /* Rows per key id over every stride-th row (stride 1 = exact counts): what a balanced owner
  * table is computed from -- Spark has no counterpart, its hash partitioning leaves a hot key's
  * task as long as it is (the skew tsdf.py:164-190 works around).  out_counts: device

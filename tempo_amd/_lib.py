@@ -99,6 +99,11 @@ class PartitionArgs(C.Structure):
                 ("split_slices", _vp), ("split_first", _vp), ("slice_owner", _vp), ("halo", C.c_int32)]
 
 
+class PartitionMoveArgs(C.Structure):
+    _fields_ = [("route", PartitionArgs), ("n_cols", C.c_int32), ("cols", _vp), ("col_bytes", _vp),
+                ("out_cols", _vp), ("capacity", C.c_int64)]
+
+
 class KeyCountsArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("stride", C.c_int32),
                 ("out_counts", _vp)]
@@ -136,6 +141,8 @@ SYMBOLS = {
     "tmp_interpolate": _OP(InterpolateArgs),
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
+    "tmp_partition_move_workspace_bytes": _WS(PartitionMoveArgs),
+    "tmp_partition_move": _OP(PartitionMoveArgs),
     "tmp_key_counts_workspace_bytes": _WS(KeyCountsArgs),
     "tmp_key_counts": _OP(KeyCountsArgs),
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),

@@ -43,8 +43,35 @@ __device__ __forceinline__ uint32_t slice_owner_of(const SliceArgs &sl, uint32_t
   return clamp_owner(sl.slice_owner[sl.split_first[slot] + slice], n_parts);
 }
 
-// Owner of every row (the digit of the bucketing pass) and the rows per owner.  In halo mode the
-// digit is the part that needs a COPY of the row, or n_parts ("none") -- counted nowhere.
+// Part of one row; `counted` = the row goes anywhere at all.  In halo mode the result is the part
+// that needs a COPY of the row, or n_parts ("none", not counted).
+__device__ __forceinline__ uint32_t route_row(uint32_t k, int64_t i, uint32_t n_parts,
+                                              const int32_t *__restrict__ table, uint32_t n_table,
+                                              const SliceArgs &sl, bool &counted) {
+  counted = true;
+  if (!table) return mix_key(k) % n_parts;
+  // balanced ownership: a small table, read by every row (stays in cache)
+  const int32_t t = k < n_table ? table[k] : 0;
+  const bool sliced = t < 0 && sl.ts && (uint32_t)(-(t + 1)) < sl.n_split;
+  if (!sliced) {
+    if (sl.halo) { counted = false; return n_parts; }
+    return clamp_owner(t, n_parts);
+  }
+  const uint32_t slot = (uint32_t)(-(t + 1));
+  const int64_t ts = sl.ts[i];
+  const int32_t q = bracket_index(ts, sl.sp);
+  const uint32_t o = slice_owner_of(sl, slot, q, n_parts);
+  if (!sl.halo) return o;
+  // the carried-over tail of bracket q is read by bracket q + 1
+  const double d = bracket_seconds(ts, sl.sp);
+  const double part = bracket_part(d, sl.sp);
+  const bool tail = (d - part) / sl.sp.v >= sl.sp.one_minus_fraction;
+  const uint32_t o2 = slice_owner_of(sl, slot, (int64_t)q + 1, n_parts);
+  counted = tail && o2 != o;
+  return counted ? o2 : n_parts;
+}
+
+// Owner of every row (the digit of the bucketing pass) and the rows per owner.
 __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64_t n, uint32_t n_parts,
                                                        const int32_t *__restrict__ table, uint32_t n_table,
                                                        SliceArgs sl, uint64_t *comp, uint32_t *idx,
@@ -62,33 +89,9 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
     const int64_t i = base + lane;
     const bool in = i < n;
     uint32_t o = 0;
-    bool counted = in;
+    bool counted = false;
     if (in) {
-      const uint32_t k = (uint32_t)key[i];
-      if (table) {  // balanced ownership: a small table, read by every row (stays in cache)
-        const int32_t t = k < n_table ? table[k] : 0;
-        const bool sliced = t < 0 && sl.ts && (uint32_t)(-(t + 1)) < sl.n_split;
-        if (sliced) {
-          const uint32_t slot = (uint32_t)(-(t + 1));
-          const int64_t ts = sl.ts[i];
-          const int32_t q = bracket_index(ts, sl.sp);
-          o = slice_owner_of(sl, slot, q, n_parts);
-          if (sl.halo) {
-            // the carried-over tail of bracket q is read by bracket q + 1
-            const double d = bracket_seconds(ts, sl.sp);
-            const double part = bracket_part(d, sl.sp);
-            const bool tail = (d - part) / sl.sp.v >= sl.sp.one_minus_fraction;
-            const uint32_t o2 = slice_owner_of(sl, slot, (int64_t)q + 1, n_parts);
-            counted = tail && o2 != o;
-            o = counted ? o2 : n_parts;
-          }
-        } else {
-          o = clamp_owner(t, n_parts);
-          if (sl.halo) { counted = false; o = n_parts; }
-        }
-      } else {
-        o = mix_key(k) % n_parts;
-      }
+      o = route_row((uint32_t)key[i], i, n_parts, table, n_table, sl, counted);
       comp[i] = o;
       idx[i] = (uint32_t)i;
     }
@@ -105,6 +108,145 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
   __syncthreads();
   for (int i = threadIdx.x; i < (int)n_parts; i += kBlock)
     if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+// ---- route and move in one go (at most 64 parts) ------------------------------------------
+// Every wave owns a contiguous range of rows.  Pass 1 notes each row's part in a byte and counts
+// the wave's rows per part; an exclusive scan over [part][wave] turns the counts into where each
+// wave's rows of each part start in the bucketed order; pass 2 walks the same ranges and copies
+// every column's value straight to its place -- no row ids, no sort passes, no barriers.
+constexpr int kMoveWavesPerBlock = kBlock / 64;
+constexpr uint8_t kNoPart = 255;
+
+struct MoveGeom {
+  int grid;
+  int waves;
+  int64_t rows_per_wave;  // multiple of 64
+};
+
+static MoveGeom move_geom(int64_t n) {
+  MoveGeom g;
+  int64_t want = (n + 64 * 64 - 1) / (64 * 64);  // at least 64 steps per wave when there is work
+  g.waves = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  g.waves = (g.waves + kMoveWavesPerBlock - 1) / kMoveWavesPerBlock * kMoveWavesPerBlock;
+  g.grid = g.waves / kMoveWavesPerBlock;
+  int64_t per = (n + g.waves - 1) / g.waves;
+  g.rows_per_wave = (per + 63) / 64 * 64;
+  if (g.rows_per_wave < 64) g.rows_per_wave = 64;
+  return g;
+}
+
+__global__ __launch_bounds__(kBlock) void route_count_kernel(const int32_t *key, int64_t n, uint32_t n_parts,
+                                                             const int32_t *__restrict__ table,
+                                                             uint32_t n_table, SliceArgs sl,
+                                                             int64_t rows_per_wave, int n_waves,
+                                                             uint8_t *__restrict__ part_of,
+                                                             uint32_t *__restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kMoveWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t lo = (int64_t)wave * rows_per_wave;
+  const int64_t hi = lo + rows_per_wave < n ? lo + rows_per_wave : n;
+  uint32_t mine = 0;  // lane p: rows of part p in this wave's range
+  constexpr int U = 4;  // rows per lane and step: the key loads of a step are issued together
+  for (int64_t base = lo; base < hi; base += 64 * U) {
+    uint32_t k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 64 + lane;
+      k[u] = i < hi ? (uint32_t)key[i] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 64 + lane;
+      bool counted = false;
+      uint32_t o = n_parts;
+      if (i < hi) {
+        o = route_row(k[u], i, n_parts, table, n_table, sl, counted);
+        part_of[i] = counted ? (uint8_t)o : kNoPart;
+      }
+      for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint64_t b = __ballot(counted && o == p);
+        if ((uint32_t)lane == p) mine += (uint32_t)__popcll(b);
+      }
+    }
+  }
+  if ((uint32_t)lane < n_parts) counts[(size_t)lane * n_waves + wave] = mine;
+}
+
+// After the scan over n_parts * n_waves + 1 entries (the last one starts at zero, so it ends up
+// holding the grand total): rows per part.
+__global__ void part_totals_kernel(const uint32_t *offsets, int n_waves, uint32_t n_parts,
+                                   unsigned long long *out) {
+  const uint32_t p = threadIdx.x;
+  if (p < n_parts) out[p] = offsets[(size_t)(p + 1) * n_waves] - offsets[(size_t)p * n_waves];
+}
+
+constexpr int kMoveCols = 12;
+struct MoveCols {
+  int n;
+  const void *src[kMoveCols];
+  void *dst[kMoveCols];
+  int bytes[kMoveCols];
+};
+
+__global__ __launch_bounds__(kBlock) void route_move_kernel(int64_t n, uint32_t n_parts, int64_t rows_per_wave,
+                                                            int n_waves, const uint8_t *__restrict__ part_of,
+                                                            const uint32_t *__restrict__ offsets,
+                                                            MoveCols mc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kMoveWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t lo = (int64_t)wave * rows_per_wave;
+  const int64_t hi = lo + rows_per_wave < n ? lo + rows_per_wave : n;
+  // lane p: where this wave's next row of part p goes
+  uint32_t run = (uint32_t)lane < n_parts ? offsets[(size_t)lane * n_waves + wave] : 0u;
+  const uint64_t below = (1ull << lane) - 1;
+  constexpr int U = 4;  // rows per lane and step
+  for (int64_t base = lo; base < hi; base += 64 * U) {
+    uint32_t o[U], dest[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * 64 + lane;
+      o[u] = i < hi ? part_of[i] : kNoPart;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      dest[u] = 0;
+      for (uint32_t p = 0; p < n_parts; ++p) {
+        const uint64_t b = __ballot(o[u] == p);
+        const uint32_t start = __shfl(run, (int)p);
+        if (o[u] == p) dest[u] = start + (uint32_t)__popcll(b & below);
+        if ((uint32_t)lane == p) run += (uint32_t)__popcll(b);
+      }
+    }
+    for (int c = 0; c < mc.n; ++c) {
+      const int bytes = mc.bytes[c];
+      if (bytes == 8) {
+        uint64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) v[u] = ((const uint64_t *)mc.src[c])[base + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) ((uint64_t *)mc.dst[c])[dest[u]] = v[u];
+      } else if (bytes == 4) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) v[u] = ((const uint32_t *)mc.src[c])[base + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) ((uint32_t *)mc.dst[c])[dest[u]] = v[u];
+      } else {
+        uint8_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) v[u] = ((const uint8_t *)mc.src[c])[base + u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (o[u] != kNoPart) ((uint8_t *)mc.dst[c])[dest[u]] = v[u];
+      }
+    }
+  }
 }
 
 // Rows per key over every stride-th row.  Small dictionaries are counted in LDS per block and
@@ -149,6 +291,35 @@ extern "C" int32_t tmp_key_owner(int32_t key, int32_t n_parts) {
   return n_parts > 0 ? (int32_t)(mix_key((uint32_t)key) % (uint32_t)n_parts) : 0;
 }
 
+static int slice_args(const tmp_partition_args *a, SliceArgs *out) {
+  SliceArgs sl;
+  memset(&sl, 0, sizeof(sl));
+  if (a->owner_table && a->ts) {
+    TMP_REQUIRE(a->n_split >= 0 && (a->n_split == 0 || (a->split_slices && a->split_first && a->slice_owner)),
+                TMP_EINVAL, "partition: sliced keys need split_slices, split_first and slice_owner");
+    TMP_REQUIRE(a->ts_partition_val > 0 && a->bracket_count >= 1, TMP_EINVAL,
+                "partition: sliced keys need ts_partition_val > 0 and bracket_count >= 1");
+    TMP_REQUIRE(!a->halo || a->n_parts <= 255, TMP_EINVAL, "partition: halo mode takes at most 255 parts");
+    sl.ts = a->ts;
+    sl.sp.enabled = 1;
+    sl.sp.v_is_int = a->v_is_int;
+    sl.sp.ts_is_seconds = a->ts_is_seconds;
+    sl.sp.v = a->ts_partition_val;
+    sl.sp.one_minus_fraction = a->one_minus_fraction;
+    sl.bracket_min = a->bracket_min;
+    sl.bracket_count = a->bracket_count;
+    sl.n_split = (uint32_t)a->n_split;
+    sl.split_slices = a->split_slices;
+    sl.split_first = a->split_first;
+    sl.slice_owner = a->slice_owner;
+    sl.halo = a->halo != 0;
+  } else {
+    TMP_REQUIRE(!a->halo, TMP_EINVAL, "partition: halo mode needs an owner table and ts");
+  }
+  *out = sl;
+  return TMP_OK;
+}
+
 extern "C" size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
@@ -176,29 +347,7 @@ extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
   TMP_REQUIRE(!a->owner_table || a->n_keys >= 1, TMP_EINVAL,
               "tmp_hash_partition: owner_table needs n_keys >= 1");
   SliceArgs sl;
-  memset(&sl, 0, sizeof(sl));
-  if (a->owner_table && a->ts) {
-    TMP_REQUIRE(a->n_split >= 0 && (a->n_split == 0 || (a->split_slices && a->split_first && a->slice_owner)),
-                TMP_EINVAL, "tmp_hash_partition: sliced keys need split_slices, split_first and slice_owner");
-    TMP_REQUIRE(a->ts_partition_val > 0 && a->bracket_count >= 1, TMP_EINVAL,
-                "tmp_hash_partition: sliced keys need ts_partition_val > 0 and bracket_count >= 1");
-    TMP_REQUIRE(!a->halo || a->n_parts <= 255, TMP_EINVAL, "tmp_hash_partition: halo mode takes at most 255 parts");
-    sl.ts = a->ts;
-    sl.sp.enabled = 1;
-    sl.sp.v_is_int = a->v_is_int;
-    sl.sp.ts_is_seconds = a->ts_is_seconds;
-    sl.sp.v = a->ts_partition_val;
-    sl.sp.one_minus_fraction = a->one_minus_fraction;
-    sl.bracket_min = a->bracket_min;
-    sl.bracket_count = a->bracket_count;
-    sl.n_split = (uint32_t)a->n_split;
-    sl.split_slices = a->split_slices;
-    sl.split_first = a->split_first;
-    sl.slice_owner = a->slice_owner;
-    sl.halo = a->halo != 0;
-  } else {
-    TMP_REQUIRE(!a->halo, TMP_EINVAL, "tmp_hash_partition: halo mode needs an owner table and ts");
-  }
+  TMP_TRY(slice_args(a, &sl));
   TMP_LAUNCH(owner_kernel, dim3(grid_for(a->n, kBlock * 8, 2048)), dim3(kBlock), st, a->key, a->n,
              (uint32_t)a->n_parts, a->owner_table, (uint32_t)(a->owner_table ? a->n_keys : 0), sl,
              b.comp[0], b.idx[0], (unsigned long long *)a->out_counts);
@@ -227,6 +376,82 @@ extern "C" int tmp_key_counts(const tmp_key_counts_args *a, void *, size_t, void
   // few blocks when the counters live in LDS: each one flushes up to n_keys counters
   TMP_LAUNCH(key_counts_kernel, dim3(grid_for(n_samples, kBlock * 64, 1024)), dim3(kBlock), st, a->key,
              n_samples, (int64_t)a->stride, (uint32_t)a->n_keys, (unsigned long long *)a->out_counts);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
+
+static void move_plan(int64_t n, int n_parts, Workspace &ws, MoveGeom *g, uint8_t **part_of,
+                      uint32_t **offsets) {
+  *g = move_geom(n);
+  *part_of = ws.take<uint8_t>((size_t)(n > 0 ? n : 1));
+  *offsets = ws.take<uint32_t>((size_t)n_parts * g->waves + 1);
+}
+
+extern "C" size_t tmp_partition_move_workspace_bytes(const tmp_partition_move_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  MoveGeom g;
+  uint8_t *part_of;
+  uint32_t *offsets;
+  move_plan(a->route.n, a->route.n_parts > 0 ? a->route.n_parts : 1, ws, &g, &part_of, &offsets);
+  return ws.off;
+}
+
+extern "C" int tmp_partition_move(const tmp_partition_move_args *a, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_partition_move: null args");
+  const tmp_partition_args *r = &a->route;
+  TMP_REQUIRE(r->n >= 0 && r->n < (1ll << 31), TMP_EINVAL, "tmp_partition_move: bad row count");
+  TMP_REQUIRE(r->n_parts >= 1 && r->n_parts <= 64, TMP_EUNSUPPORTED,
+              "tmp_partition_move: 1 to 64 parts (use tmp_hash_partition + tmp_gather beyond)");
+  TMP_REQUIRE(r->out_counts, TMP_EINVAL, "tmp_partition_move: out_counts is null");
+  TMP_REQUIRE(a->n_cols >= 0 && a->n_cols <= kMoveCols, TMP_EUNSUPPORTED,
+              "tmp_partition_move: at most %d columns per call", kMoveCols);
+  TMP_REQUIRE(a->capacity >= 0, TMP_EINVAL, "tmp_partition_move: negative capacity");
+  hipStream_t st = (hipStream_t)stream;
+  TMP_CHECK_HIP(hipMemsetAsync(r->out_counts, 0, sizeof(int64_t) * r->n_parts, st));
+  if (r->n == 0) return TMP_OK;
+  TMP_REQUIRE(r->key, TMP_EINVAL, "tmp_partition_move: null key column");
+  TMP_REQUIRE(!r->owner_table || r->n_keys >= 1, TMP_EINVAL, "tmp_partition_move: owner_table needs n_keys >= 1");
+  MoveCols mc;
+  memset(&mc, 0, sizeof(mc));
+  mc.n = a->n_cols;
+  for (int c = 0; c < a->n_cols; ++c) {
+    TMP_REQUIRE(a->cols && a->out_cols && a->col_bytes && a->cols[c] && a->out_cols[c], TMP_EINVAL,
+                "tmp_partition_move: null column %d", c);
+    TMP_REQUIRE(a->col_bytes[c] == 1 || a->col_bytes[c] == 4 || a->col_bytes[c] == 8, TMP_EUNSUPPORTED,
+                "tmp_partition_move: column %d has %d-byte elements (1, 4 or 8 supported)", c, a->col_bytes[c]);
+    mc.src[c] = a->cols[c];
+    mc.dst[c] = a->out_cols[c];
+    mc.bytes[c] = a->col_bytes[c];
+  }
+  SliceArgs sl;
+  TMP_TRY(slice_args(r, &sl));
+  Workspace ws(workspace, workspace_bytes);
+  MoveGeom g;
+  uint8_t *part_of;
+  uint32_t *offsets;
+  move_plan(r->n, r->n_parts, ws, &g, &part_of, &offsets);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_partition_move: workspace too small");
+  const int n_entries = r->n_parts * g.waves + 1;
+  TMP_CHECK_HIP(hipMemsetAsync(offsets + n_entries - 1, 0, sizeof(uint32_t), st));
+  TMP_LAUNCH(route_count_kernel, dim3(g.grid), dim3(kBlock), st, r->key, r->n, (uint32_t)r->n_parts,
+             r->owner_table, (uint32_t)(r->owner_table ? r->n_keys : 0), sl, g.rows_per_wave, g.waves,
+             part_of, offsets);
+  TMP_TRY(scan_u32_inplace(offsets, n_entries, st));
+  TMP_LAUNCH(part_totals_kernel, dim3(1), dim3(64), st, offsets, g.waves, (uint32_t)r->n_parts,
+             (unsigned long long *)r->out_counts);
+  // the copies may only run when everything fits: in halo mode the number of rows is not known
+  // beforehand, so the total is read back first (one small device->host read)
+  uint32_t total = 0;
+  TMP_CHECK_HIP(hipMemcpyAsync(&total, offsets + n_entries - 1, sizeof(total), hipMemcpyDeviceToHost, st));
+  TMP_CHECK_HIP(hipStreamSynchronize(st));
+  TMP_REQUIRE((int64_t)total <= a->capacity, TMP_ECAPACITY,
+              "tmp_partition_move: %u rows to move, room for %lld", total, (long long)a->capacity);
+  if (total > 0 && a->n_cols > 0)
+    TMP_LAUNCH(route_move_kernel, dim3(g.grid), dim3(kBlock), st, r->n, (uint32_t)r->n_parts,
+               g.rows_per_wave, g.waves, part_of, offsets, mc);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

@@ -222,21 +222,32 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     partition_fn / take_fn default to the HIP kernels; tests on CPU inject host equivalents.
     """
     world = dist.get_world_size(group)
-    partition_fn = partition_fn or _hip_partition
-    take_fn = take_fn or _hip_take
     sliced = owners is not None and owners.slices is not None
     if sliced and ts is None:
         raise ValueError("an owner plan with time slices needs the table's ts column")
-    if owners is None:
-        perm, counts = partition_fn(key, world)
-    elif sliced:
-        perm, counts = partition_fn(key, world, owners.table, owners.slices, ts)
-    else:
-        perm, counts = partition_fn(key, world, owners.table)
-    parts = [(perm, counts)]
-    if sliced and halo:
-        parts.append(partition_fn(key, world, owners.table, owners.slices, ts, True))
-    send = torch.stack([c.to(torch.int64) for _, c in parts])          # [1 or 2][world]
+    table = None if owners is None else owners.table
+    slices = owners.slices if sliced else None
+    cols = [key] + list(columns)
+    routes = [False, True] if (sliced and halo) else [False]
+    parts = []  # per route: (rows per destination, the columns in bucketed order)
+    fused = partition_fn is None and take_fn is None and world <= 64 and len(cols) <= 12
+    partition_fn = partition_fn or _hip_partition
+    take_fn = take_fn or _hip_take
+    for copies in routes:
+        if fused:    # one device call routes the rows and moves every column
+            staged, counts = ops.partition_move(key, cols, world, table, slices, ts if sliced else None, copies)
+        else:
+            if owners is None:
+                perm, counts = partition_fn(key, world)
+            elif sliced:
+                perm, counts = partition_fn(key, world, table, slices, ts, copies)
+            else:
+                perm, counts = partition_fn(key, world, table)
+            if copies:
+                perm = perm[:int(counts.sum())]
+            staged = [take_fn(c, perm) for c in cols]
+        parts.append((counts, staged))
+    send = torch.stack([c.to(torch.int64) for c, _ in parts])          # [1 or 2][world]
     recv = torch.empty_like(send)
     for i in range(len(parts)):
         dist.all_to_all_single(recv[i], send[i], group=group)
@@ -246,14 +257,14 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     send_l, recv_l, biggest = send.cpu().tolist(), recv.cpu().tolist(), biggest.cpu().tolist()
     n_recv = [sum(r) for r in recv_l]
     works, staged_all, out_cols = [], [], []
-    for col in [key] + list(columns):
+    for ci, col in enumerate(cols):
         got = torch.empty(sum(n_recv), dtype=col.dtype, device=col.device)
         rows_per_round = max(1, MAX_MESSAGE_BYTES // col.element_size())
         at = 0
-        for i, (p, _) in enumerate(parts):
+        for i, (_, staged_cols) in enumerate(parts):
             if int(biggest[i]) == 0:  # nothing to move anywhere (all ranks agree on that)
                 continue
-            staged = take_fn(col, p if i == 0 else p[:sum(send_l[i])])
+            staged = staged_cols[ci]
             rounds = max(1, -(-int(biggest[i]) // rows_per_round))
             works += _exchange(staged, got[at:at + n_recv[i]], send_l[i], recv_l[i], rounds, rows_per_round, group)
             staged_all.append(staged)

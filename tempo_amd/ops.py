@@ -438,22 +438,12 @@ def interpolate(key, ts, n_keys, freq_us, method, cols, cols_valid):
                 valid=[valid[c, :m] for c in range(k)], interp=[interp[c, :m] for c in range(k)])
 
 
-def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=False):
-    """Bucket rows by owner: owner_table[key] when a table (int32[n_keys], device) is given, else
-    hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts]).
-
-    slices (with ts): time-sliced ownership of hot keys for the skew AS-OF join -- a dict with
-    ts_partition_val, v_is_int, one_minus_fraction, ts_is_seconds, bracket_min, bracket_count and
-    the device int32 tensors split_slices, split_first, slice_owner (include/tempo_hip.h,
-    tmp_partition_args).  halo=True routes the copies of carried-over rows instead of the rows;
-    only the first counts.sum() entries of perm are meaningful then."""
+def _route_args(a, key, n_parts, owner_table, slices, ts, halo):
     n = key.numel()
     _dev(key, torch.int32, "key")
     _dev(owner_table, torch.int32, "owner_table")
-    perm = torch.empty(n, dtype=torch.int32, device=key.device)
-    counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
-    a = PartitionArgs(n, _p(key), int(n_parts), _p(perm), _p(counts), _p(owner_table),
-                      0 if owner_table is None else owner_table.numel())
+    a.n, a.key, a.n_parts = n, _p(key), int(n_parts)
+    a.owner_table, a.n_keys = _p(owner_table), 0 if owner_table is None else owner_table.numel()
     if slices is not None:
         _dev(ts, torch.int64, "ts", n)
         for name in ("split_slices", "split_first", "slice_owner"):
@@ -467,10 +457,60 @@ def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=Fa
         a.halo = int(bool(halo))
     elif halo:
         raise ValueError("halo routing needs sliced keys")
+
+
+def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=False):
+    """Bucket rows by owner: owner_table[key] when a table (int32[n_keys], device) is given, else
+    hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts]).
+
+    slices (with ts): time-sliced ownership of hot keys for the skew AS-OF join -- a dict with
+    ts_partition_val, v_is_int, one_minus_fraction, ts_is_seconds, bracket_min, bracket_count and
+    the device int32 tensors split_slices, split_first, slice_owner (include/tempo_hip.h,
+    tmp_partition_args).  halo=True routes the copies of carried-over rows instead of the rows;
+    only the first counts.sum() entries of perm are meaningful then."""
+    perm = torch.empty(key.numel(), dtype=torch.int32, device=key.device)
+    counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
+    a = PartitionArgs()
+    _route_args(a, key, n_parts, owner_table, slices, ts, halo)
+    a.out_perm, a.out_counts = _p(perm), _p(counts)
     ws = _workspace(lib().tmp_hash_partition_workspace_bytes(C.byref(a)), key.device)
     check(lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
           "tmp_hash_partition")
     return perm, counts
+
+
+def partition_move(key, columns, n_parts, owner_table=None, slices=None, ts=None, halo=False):
+    """Route rows like hash_partition and move `columns` (1-, 4- or 8-byte elements, at most 12)
+    into bucketed order in the same call (n_parts <= 64).  Returns ([bucketed columns],
+    counts int64[n_parts]); part r's rows sit at [sum(counts[:r]), sum(counts[:r+1])) in input
+    order.  In halo mode the outputs hold just the copies (counts.sum() rows)."""
+    n = key.numel()
+    for i, c in enumerate(columns):
+        _dev(c, c.dtype, f"columns[{i}]", n)
+        if c.element_size() not in (1, 4, 8):
+            raise TypeError("partition_move columns must have 1-, 4- or 8-byte elements")
+    counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
+    capacity = max(1024, n // 64) if halo else n
+    while True:
+        outs = [torch.empty(capacity, dtype=c.dtype, device=c.device) for c in columns]
+        a = _lib.PartitionMoveArgs()
+        _route_args(a.route, key, n_parts, owner_table, slices, ts, halo)
+        a.route.out_counts = _p(counts)
+        keep = [ptr_array([c.data_ptr() for c in columns]), ptr_array([c.data_ptr() for c in outs]),
+                (C.c_int32 * max(len(columns), 1))(*[c.element_size() for c in columns])]
+        a.n_cols, a.cols, a.out_cols, a.col_bytes = len(columns), C.cast(keep[0], C.c_void_p), \
+            C.cast(keep[1], C.c_void_p), C.cast(keep[2], C.c_void_p)
+        a.capacity = capacity
+        ws = _workspace(lib().tmp_partition_move_workspace_bytes(C.byref(a)), key.device)
+        rc = lib().tmp_partition_move(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+        if rc == _lib.TMP_ECAPACITY and capacity < n:
+            capacity = n if not halo else min(n, int(counts.sum().item()))
+            continue
+        check(rc, "tmp_partition_move")
+        if halo:
+            m = int(counts.sum().item())
+            outs = [o[:m] for o in outs]
+        return outs, counts
 
 
 def key_counts(key, n_keys, stride=1):

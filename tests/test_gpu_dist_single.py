@@ -187,3 +187,37 @@ def test_shuffle_with_sliced_plan_single_rank_nccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(400_000, 8), (70_001, 3), (50, 2), (1_300_000, 64), (0, 4)])
+def test_partition_move_equals_partition_plus_gather(n, world):
+    """The fused route-and-move call delivers what tmp_hash_partition + one gather per column
+    do: hashed owners, an owner table, time slices and the halo copies; 1-, 4- and 8-byte columns."""
+    from tempo_amd import ops
+    from tempo_amd.dist import plan_owners
+    rng = np.random.default_rng(n + world)
+    n_keys = 40
+    kl, tl, kr, tr = _skew_tables(rng, max(n, 1), n_keys, 0.45)
+    key, ts = kr[:n], tr[:n]
+    cols = [key, ts, rng.normal(0, 1, n), (rng.random(n) > 0.5).astype(np.uint8), rng.integers(0, 9, n).astype(np.int32)]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dcols = [d(c) for c in cols]
+    counts = np.bincount(key, minlength=n_keys) * 2
+    plans = [(None, None)]
+    if n:
+        plain = plan_owners(counts, world, torch.device("cuda"))
+        sliced = plan_owners(counts, world, torch.device("cuda"), skew=dict(ts_partition_val=10, fraction=0.1),
+                             ts_range=(int(ts.min()), int(ts.max())))
+        plans += [(plain.table, None), (sliced.table, sliced.slices)]
+    for table, slices in plans:
+        for halo in ([False, True] if slices is not None else [False]):
+            dts = dcols[1] if slices is not None else None
+            perm, cnt = ops.hash_partition(dcols[0], world, table, slices, dts, halo)
+            outs, cnt2 = ops.partition_move(dcols[0], dcols, world, table, slices, dts, halo)
+            torch.cuda.synchronize()
+            assert np.array_equal(cnt.cpu().numpy(), cnt2.cpu().numpy())
+            m = int(cnt.sum())
+            assert m == n or halo
+            p = perm.cpu().numpy()[:m]
+            for c, o in zip(cols, outs):
+                assert np.array_equal(o.cpu().numpy()[:m], c[p])
