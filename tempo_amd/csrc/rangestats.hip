@@ -171,13 +171,18 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
                                                                  uint64_t w, RsOut<T> o,
-                                                                 int32_t *deferred) {
+                                                                 int32_t *deferred, int n_tiles) {
   constexpr bool kInt = ((T)0.5 == (T)0);
   __shared__ RsShared<T> s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int low = lay.low_bits;
   const uint64_t pmask = lay.prim_mask();
-  const int64_t t0 = (int64_t)blockIdx.x * RK_ROWS;
+  // Workgroups go to the 8 XCDs round-robin; neighbouring tiles stage overlapping regions, so the
+  // tiles are dealt out such that each XCD (one L2) works through one contiguous eighth of them.
+  const int per_xcd = (n_tiles + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= n_tiles) return;
+  const int64_t t0 = (int64_t)tile * RK_ROWS;
   const int64_t t1 = t0 + RK_ROWS < n ? t0 + RK_ROWS : n;
   // staged region [rs, re): the tile, RK_FWD rows after it (later same-second peers) and as many
   // rows before it as fit
@@ -523,10 +528,11 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
-  int grid = (int)((a->n + RK_ROWS - 1) / RK_ROWS);
+  const int n_tiles = (int)((a->n + RK_ROWS - 1) / RK_ROWS);
+  int grid = (n_tiles + 7) / 8 * 8;
   TMP_CHECK_HIP(hipMemsetAsync(p.deferred, 0, sizeof(int32_t), st));
   TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm,
-                     xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred);
+                     xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred, n_tiles);
   TMP_CHECK_HIP(hipGetLastError());
   // one small blocking read: did any frame leave its block's region?
   int32_t deferred = 0;
