@@ -137,8 +137,13 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TEMPO_BENCH_BACKEND=gloo rehearses the --gpus N path where RCCL has no peers: ranks may then
+    # share a GPU (rank r uses device r modulo the number of devices) and the exchange is staged
+    # through host memory.  The default, and the only measured configuration, is RCCL.
+    backend = os.environ.get("TEMPO_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     # TEMPO_BENCH_FORCE_SHUFFLE=1 runs the shuffle path on one GPU too (a one-rank RCCL group):
     # a way to rehearse the --gpus N code path where only one GPU is at hand
@@ -149,12 +154,22 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-        from tempo_amd.dist import balanced_owners, shuffle_by_key_start
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        from tempo_amd.dist import all_reduce, balanced_owners, shuffle_by_key_start
+
+    verbose = os.environ.get("TEMPO_BENCH_VERBOSE") == "1"
+
+    def log(msg):
+        if verbose:
+            print("[rank %d %.3f] %s" % (rank, time.perf_counter(), msg), file=sys.stderr, flush=True)
 
     rows = args.rows
     n_left = n_right = rows // 2
     ASOF_KEYS, TICK_KEYS = 10_000, 100
+    log("process group up, generating tables")
     tq = gen_trades_quotes(dev, n_left, n_right, ASOF_KEYS, 4567 + rank)
     tk = gen_ticks(dev, rows, TICK_KEYS, 2345 + rank)
     torch.cuda.synchronize()
@@ -178,12 +193,14 @@ def main():
                                        skew=dict(ts_partition_val=10, fraction=0.1),
                                        ts=[tq["ts_l"], tq["ts_r"]])
             own_ticks = balanced_owners(tk["key"], TICK_KEYS)
+            log("owner plans ready (join keys sliced: %s)" % (own_join.slices is not None))
             p_trades = shuffle_by_key_start(tq["key_l"], [tq["ts_l"], tq["trade_pr"]], owners=own_join,
                                             ts=tq["ts_l"])
             p_quotes = shuffle_by_key_start(
                 tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]],
                 owners=own_join, ts=tq["ts_r"], halo=True)
             p_ticks = shuffle_by_key_start(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]], owners=own_ticks)
+            log("exchanges issued")
             kl, (tl, pr), _, _ = p_trades.wait()
             kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
             q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
@@ -194,7 +211,8 @@ def main():
             q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
             [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
             skip_nulls=True, ts_partition_val=10, fraction=0.1)
-        n1 = q["ts_l"].numel() + q["ts_r"].numel()
+        n1 = (q["ts_l"].numel(), q["ts_r"].numel())
+        log("join enqueued on %d + %d rows" % n1)
         del j
         _lib.profile_tag(2)
         if dist is not None:
@@ -202,6 +220,7 @@ def main():
             t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
         out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
         n2 = t["ts"].numel()
+        log("range stats enqueued on %d rows" % n2)
         del out
         return n1, n2
 
@@ -213,10 +232,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows_done = 0
     for _ in range(args.steps):
         n1, n2 = step()
-        rows_done += n1 + n2
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -224,11 +241,18 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rows_done], dtype=torch.int64, device=dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rows_done = int(r.item())
+        # what the ranks held after the last step's shuffle: every trade and tick exactly once,
+        # every quote once plus the few carried across a time-slice boundary
+        r = torch.tensor([n1[0], n1[1], n2], dtype=torch.int64, device=dev)
+        all_reduce(r, dist.ReduceOp.SUM)
+        held = [int(v) for v in r.tolist()]
+        if held[0] != world * n_left or held[2] != world * rows or not (
+                world * n_right <= held[1] <= world * n_right * 1.01):
+            sys.exit("bench.py: rows lost or duplicated by the shuffle: %r" % (held,))
+    # rows the two operators consumed: the generated tables, whatever rank processed them
+    rows_done = args.steps * world * (n_left + n_right + rows)
 
     # ---- per-kernel device time from the HIP events recorded on the launch stream
     roofline = None

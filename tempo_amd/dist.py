@@ -104,7 +104,7 @@ def balanced_owners(keys, n_keys, group=None, stride=16, counts_fn=None, skew=No
     for k in keys:
         c = counts_fn(k, n_keys, stride)
         total = c if total is None else total + c
-    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(total, dist.ReduceOp.SUM, group)
     counts = total.cpu().numpy().astype(np.int64)
     dev = keys[0].device
     ts_range = None
@@ -115,7 +115,7 @@ def balanced_owners(keys, n_keys, group=None, stride=16, counts_fn=None, skew=No
         lo = min([int(t.min()) for t in ts if t.numel()] or [big])
         hi = max([int(t.max()) for t in ts if t.numel()] or [-big])
         ends = torch.tensor([lo, -hi], dtype=torch.int64, device=dev)
-        dist.all_reduce(ends, op=dist.ReduceOp.MIN, group=group)
+        all_reduce(ends, dist.ReduceOp.MIN, group)
         ts_range = (int(ends[0]), -int(ends[1]))
     return plan_owners(counts, world, dev, skew, ts_range)
 
@@ -164,10 +164,41 @@ def plan_owners(counts, world, device, skew=None, ts_range=None):
     return OwnerPlan(torch.from_numpy(assign_owners(counts, world)).to(device))
 
 
+def _host_staged(group, t):
+    """gloo has no all-to-all for device tensors: under it (rehearsals of the multi-rank path on a
+    box without RCCL peers, several ranks sharing one GPU) the exchange is staged through host
+    memory.  RCCL is the production path."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce(t, op, group=None):
+    """dist.all_reduce, through host memory under gloo (see _host_staged)."""
+    if _host_staged(group, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _counts_all_to_all(recv, send, group):
+    if _host_staged(group, send):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+
+
 def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
     """All-to-all of one column in `rounds` slices: round c moves rows [c*R, (c+1)*R) of what
     every rank sends to every other rank.  Views only, nothing is copied.  Returns the pending
     work handles (the collectives are issued asynchronously, in order)."""
+    if _host_staged(group, staged):
+        h_got = torch.empty(got.shape, dtype=got.dtype)
+        dist.all_to_all_single(h_got, staged.cpu(), output_split_sizes=recv_l, input_split_sizes=send_l, group=group)
+        got.copy_(h_got)
+        return []
     s_off = [0]
     for v in send_l[:-1]:
         s_off.append(s_off[-1] + v)
@@ -250,10 +281,10 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     send = torch.stack([c.to(torch.int64) for c, _ in parts])          # [1 or 2][world]
     recv = torch.empty_like(send)
     for i in range(len(parts)):
-        dist.all_to_all_single(recv[i], send[i], group=group)
+        _counts_all_to_all(recv[i], send[i], group)
     # every rank must run the same number of rounds: size them by the largest pairwise message
     biggest = torch.maximum(send.max(dim=1).values, recv.max(dim=1).values)
-    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    all_reduce(biggest, dist.ReduceOp.MAX, group)
     send_l, recv_l, biggest = send.cpu().tolist(), recv.cpu().tolist(), biggest.cpu().tolist()
     n_recv = [sum(r) for r in recv_l]
     works, staged_all, out_cols = [], [], []
