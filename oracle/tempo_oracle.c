@@ -13,7 +13,8 @@
  * Parity status: pinned by the golden vectors of the reference's own tests
  * (python/tests/tsdf_tests.py:164-394 asofJoin, :444-502 withRangeStats to 2 decimals,
  * :580-660 resample; scala EMATests.scala:19-43 for the EMA formula).  withLookbackFeatures
- * and the Python EMA have no reference test: parity unpinned for those two.
+ * and the Python EMA have no reference test: parity unpinned for those two, and for the derived
+ * columns of the table writer (tsdf_tests.py:746-787 counts rows only).
  *
  * Conventions: timestamps are int64 microseconds since the epoch (Spark TimestampType) unless
  * ts_is_seconds!=0 (an integral ts column); partition keys are dictionary ids (int32);
