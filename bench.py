@@ -301,6 +301,14 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rows_done / elapsed
+        # whole-step view ("% HBM peak" of the metric): the operators' compulsory bytes -- every
+        # input read once, every output written once, no sort pass or scratch credited --
+        # asofJoin: 12 B key/ts per row of both sides + 3 joined 8-byte columns read and written;
+        # withRangeStats: 12 B key/ts + 8 B metric read, 7 x 8 B written
+        step_bytes = world * ((n_left + n_right) * 12 + (n_left + n_right) * 24 + rows * (12 + 8 + 56))
+        if roofline is not None:
+            roofline["step_algorithmic_bytes"] = step_bytes
+            roofline["step_frac_of_peak"] = round(step_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
         top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:8]
         line = {
             "metric": "AS-OF join + withRangeStats rows/sec at 1B rows (1-8 GPU); % HBM peak",
