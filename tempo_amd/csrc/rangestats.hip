@@ -228,31 +228,36 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
   const int pat = s.pivot_at;
   const double pivot = pat < RK_CAP ? (double)s.x[pat] : 0.0;
 
-  // ---- per 8-slot sub-block aggregates straight from registers (a sub-block = half a DPP row)
+  // ---- per 8-slot sub-block aggregates: one thread per sub-block adds its eight staged slots up
+  //      in registers (a few waves' worth of plain adds instead of cross-lane scans in every wave)
+  if (tid < RK_NSB) {
+    const int b = tid;
+    double sd = 0.0, sq = 0.0;
+    uint32_t sc = 0;
+    uint64_t si = 0;
+    T vmn = MinMax<T>::min_identity(), vmx = MinMax<T>::max_identity();
+    const uint4 c0 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB]);
+    const uint4 c1 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB + 4]);
+    const uint32_t cs[RK_SB] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-  for (int r = 0; r < kPer; ++r) {
-    int e = r * RK_THREADS + tid;
-    if (e < RK_CAP) {  // uniform per wave: RK_CAP and RK_THREADS are multiples of 64
-      double d = fin[r] ? (double)xv[r] - pivot : 0.0;
-      double sd = row_sum_f64(d);
-      double sq = row_sum_f64(d * d);
-      uint32_t sc = row_sum_u32((ok[r] ? 1u : 0u) | ((ok[r] && !fin[r]) ? 0x10000u : 0u));
-      T vmn = ok[r] ? xv[r] : MinMax<T>::min_identity();
-      T vmx = ok[r] ? xv[r] : MinMax<T>::max_identity();
-      vmn = MinMax<T>::row_min(vmn);
-      vmx = MinMax<T>::row_max(vmx);
-      uint64_t si = 0;
-      if (kInt) si = row_sum_u64(ok[r] ? (uint64_t)xv[r] : 0ull);
-      if ((lane & 7) == 7) {
-        int b = e >> 3;
-        s.bs[b + 1] = sd;  // shifted by one: turned into exclusive prefixes below
-        s.bq[b + 1] = sq;
-        s.bc[b + 1] = sc;
-        if (kInt) s.bi[b + 1] = si;
-        s.mn0[b] = vmn;
-        s.mx0[b] = vmx;
-      }
+    for (int j = 0; j < RK_SB; ++j) {
+      const T v = s.x[b * RK_SB + j];
+      const bool okj = (cs[j] & 1u) != 0;
+      const bool finj = okj && Ord<T>::finite(v);
+      const double d = finj ? (double)v - pivot : 0.0;
+      sd += d;
+      sq += d * d;
+      sc += (okj ? 1u : 0u) | ((okj && !finj) ? 0x10000u : 0u);
+      vmn = MinMax<T>::mn(vmn, okj ? v : MinMax<T>::min_identity());
+      vmx = MinMax<T>::mx(vmx, okj ? v : MinMax<T>::max_identity());
+      if (kInt) si += okj ? (uint64_t)v : 0ull;
     }
+    s.bs[b + 1] = sd;  // shifted by one: turned into exclusive prefixes below
+    s.bq[b + 1] = sq;
+    s.bc[b + 1] = sc;
+    if (kInt) s.bi[b + 1] = si;
+    s.mn0[b] = vmn;
+    s.mx0[b] = vmx;
   }
   __syncthreads();
 
