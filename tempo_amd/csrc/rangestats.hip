@@ -23,15 +23,14 @@ constexpr int RK_ROWS = 1024;
 constexpr int RK_CAP = 2560;
 constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
-constexpr int RK_SB = 8;                 // slots per sub-block (half a DPP row)
+constexpr int RK_SB = 8;                 // slots per sub-block
 constexpr int RK_NSB = RK_CAP / RK_SB;  // 320
 constexpr int RK_GRP = 16;              // sub-blocks per group (one DPP row of lanes)
 constexpr int RK_NGRP = RK_NSB / RK_GRP;  // 20
 constexpr int RK_GLEVELS = 5;           // sparse table over the groups: spans up to 16 of them
 static_assert(RK_NSB % 64 == 0 && RK_NGRP <= 32, "group scans are laid out for whole waves");
 
-// ---- 8-lane inclusive scans inside a DPP row (row_shr 1, 2, 4): lanes 7 and 15 of every row
-//      end up with the totals of their 8-lane halves.
+// ---- DPP moves inside a 16-lane row (used by the min / max scans over groups of sub-blocks)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int old, int v, bool bound_zero) {
   return bound_zero ? __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true)
@@ -51,28 +50,6 @@ __device__ __forceinline__ uint64_t dpp_u64(uint64_t v, bool bound_zero) {
   hi = dpp_i32<CTRL>(hi, hi, bound_zero);
   return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
-// row_shr:1/2/4 = 0x111 / 0x112 / 0x114
-#define TMP_ROW_SCAN(expr_shr) expr_shr(0x111) expr_shr(0x112) expr_shr(0x114)
-
-__device__ __forceinline__ double row_sum_f64(double v) {
-#define S_(c) v += dpp_f64<c>(v, true);
-  TMP_ROW_SCAN(S_)
-#undef S_
-  return v;
-}
-__device__ __forceinline__ uint64_t row_sum_u64(uint64_t v) {
-#define S_(c) v += dpp_u64<c>(v, true);
-  TMP_ROW_SCAN(S_)
-#undef S_
-  return v;
-}
-__device__ __forceinline__ uint32_t row_sum_u32(uint32_t v) {
-#define S_(c) v += (uint32_t)dpp_i32<c>(0, (int)v, true);
-  TMP_ROW_SCAN(S_)
-#undef S_
-  return v;
-}
-
 // min / max over staged slots.  double: NULL slots hold NaN, and fmin / fmax return the other
 // operand for a NaN, so the identity is NaN (frames that hold real NaN / inf values never take
 // this path).  int64: identities are the type's extremes.
@@ -85,18 +62,6 @@ struct MinMax<double> {
   static __device__ __forceinline__ double max_identity() { return __builtin_nan(""); }
   static __device__ __forceinline__ double mn(double a, double b) { return fmin(a, b); }
   static __device__ __forceinline__ double mx(double a, double b) { return fmax(a, b); }
-  static __device__ __forceinline__ double row_min(double v) {
-#define S_(c) v = fmin(v, dpp_f64<c>(v, false));
-    TMP_ROW_SCAN(S_)
-#undef S_
-    return v;
-  }
-  static __device__ __forceinline__ double row_max(double v) {
-#define S_(c) v = fmax(v, dpp_f64<c>(v, false));
-    TMP_ROW_SCAN(S_)
-#undef S_
-    return v;
-  }
 };
 template <>
 struct MinMax<int64_t> {
@@ -105,18 +70,6 @@ struct MinMax<int64_t> {
   static __device__ __forceinline__ int64_t max_identity() { return INT64_MIN; }
   static __device__ __forceinline__ int64_t mn(int64_t a, int64_t b) { return a < b ? a : b; }
   static __device__ __forceinline__ int64_t mx(int64_t a, int64_t b) { return a > b ? a : b; }
-  static __device__ __forceinline__ int64_t row_min(int64_t v) {
-#define S_(c) { int64_t t = (int64_t)dpp_u64<c>((uint64_t)v, false); v = t < v ? t : v; }
-    TMP_ROW_SCAN(S_)
-#undef S_
-    return v;
-  }
-  static __device__ __forceinline__ int64_t row_max(int64_t v) {
-#define S_(c) { int64_t t = (int64_t)dpp_u64<c>((uint64_t)v, false); v = t > v ? t : v; }
-    TMP_ROW_SCAN(S_)
-#undef S_
-    return v;
-  }
 };
 
 // Inclusive scans of min / max along a 16-lane DPP row: forward (row_shr 1, 2, 4, 8) gives every
