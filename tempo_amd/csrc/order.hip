@@ -199,6 +199,7 @@ struct GenArgs {
   Layout lay;
   int n_masks;
   MaskPtrs masks;
+  int id_bits;  // > 0: the radix passes carry the row id in that many bits below the word
 };
 
 __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
@@ -252,7 +253,8 @@ static SortGeom sort_geom(int64_t n, int tile) {
 
 // GEN: the launch is the first pass's histogram and builds the sort words on the way (it writes
 // them to `words`; the row ids of a first pass are the positions and are never stored).
-template <int RS_THREADS, int RS_ITEMS, int RS_BITS, bool GEN>
+// GEN == 2: the words also take the row id into their low gen.id_bits bits.
+template <int RS_THREADS, int RS_ITEMS, int RS_BITS, int GEN>
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
     uint64_t w;
     if (GEN) {
       w = make_word(gen, i);
+      if (GEN == 2) w = (w << gen.id_bits) | (uint64_t)i;
       words[i] = w;
     } else {
       w = keys[i];
@@ -359,12 +362,17 @@ int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
 // (src[row id]) and written next to the pair -- used on the last pass so that ordered copies
 // of payload columns cost no separate random gather (the scatter writes them in digit runs).
 // FIRST: the pass is the first one, its row ids are the positions themselves (not read).
-template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST>
+// PACK: the words carry the row id in their low id_bits bits (narrow sort words leave room for
+// it), so a pass moves one 8-byte stream instead of a word and an id.  1 = packed in and out
+// (every pass but the last), 2 = packed in, and out come the plain word and the row id, both
+// written from the one staged copy (the last pass).  0 = separate row ids.
+template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int PACK>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
-    PayPtrs pp) {
+    PayPtrs pp, int id_bits) {
   constexpr bool PAY = NPAY > 0;
+  const uint64_t id_mask = PACK ? ((1ull << id_bits) - 1) : 0ull;
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   constexpr int RS_RADIX = 1 << RS_BITS;
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       int64_t g = base0 + wave * (64 * RS_ITEMS) + it * 64 + lane;
       bool valid = g < n;
       kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
-      vn[PREFETCH ? it : 0] = valid ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
+      vn[PREFETCH ? it : 0] = (valid && !PACK) ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
     }
   }
   for (int t = 0; t < tiles_per_block; ++t) {
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
         k[it] = kn[PREFETCH ? it : 0];
-        v[it] = vn[PREFETCH ? it : 0];
+        v[it] = PACK ? (uint32_t)(k[it] & id_mask) : vn[PREFETCH ? it : 0];
       }
       if (t + 1 < tiles_per_block) {
         int64_t next_base = tile_base + RS_TILE;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
           int64_t g = next_base + wave * (64 * RS_ITEMS) + it * 64 + lane;
           bool valid = g < n;
           kn[PREFETCH ? it : 0] = valid ? kin[g] : 0ull;
-          vn[PREFETCH ? it : 0] = valid ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
+          vn[PREFETCH ? it : 0] = (valid && !PACK) ? (FIRST ? (uint32_t)g : vin[g]) : 0u;
         }
       }
     } else {
@@ -512,27 +520,36 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint64_t kk = sbuf[p];
         uint32_t d = (uint32_t)(kk >> shift) & mask;
         gpos[j] = goff[d] + ((uint32_t)p - dstart[d]);
-        kout[gpos[j]] = kk;
+        kout[gpos[j]] = PACK == 2 ? kk >> id_bits : kk;
       }
     }
-    __syncthreads();
-    // row ids through the same buffer (read only now unless the payload needed them: fewer
-    // registers live while the tile is ranked)
+    if (PACK == 2) {  // the row ids, from the same staged copy, as a stream of their own
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-      if (!PAY) v[it] = pos < tile_n ? (FIRST ? (uint32_t)(tile_base + pos) : vin[tile_base + pos]) : 0u;
+      for (int j = 0; j < RS_ITEMS; ++j) {
+        int p = tid + j * RS_THREADS;
+        if (p < tile_n) vout[gpos[j]] = (uint32_t)(sbuf[p] & id_mask);
+      }
     }
+    if (PACK == 0) {
+      __syncthreads();
+      // row ids through the same buffer (read only now unless the payload needed them: fewer
+      // registers live while the tile is ranked)
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-      int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-      if (pos < tile_n) sbuf32[rank[it]] = v[it];
-    }
-    __syncthreads();
+      for (int it = 0; it < RS_ITEMS; ++it) {
+        int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+        if (!PAY) v[it] = pos < tile_n ? (FIRST ? (uint32_t)(tile_base + pos) : vin[tile_base + pos]) : 0u;
+      }
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-      int p = tid + j * RS_THREADS;
-      if (p < tile_n) vout[gpos[j]] = sbuf32[p];
+      for (int it = 0; it < RS_ITEMS; ++it) {
+        int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+        if (pos < tile_n) sbuf32[rank[it]] = v[it];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < RS_ITEMS; ++j) {
+        int p = tid + j * RS_THREADS;
+        if (p < tile_n) vout[gpos[j]] = sbuf32[p];
+      }
     }
     if (PAY) {
 #pragma unroll
@@ -622,41 +639,65 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 // One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.  gen != nullptr: the
 // pass is the first one over freshly laid out rows -- its histogram kernel builds the sort words
 // (into b.comp[cur]) and its row ids are the positions.
+template <int THREADS, int ITEMS, int NPAY, int BITS, int PACK>
+static void radix_scatter_launch(OrderBuffers &b, int64_t n, int cur, int shift, uint32_t mask, int nbits,
+                                 hipStream_t st, const PayPtrs &pp, bool first, const SortGeom &g,
+                                 int id_bits) {
+  if (first)
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, PACK>), dim3(g.grid), dim3(THREADS),
+                       0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
+                       g.tiles_per_block, b.counts, pp, id_bits);
+  else
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, false, PACK>), dim3(g.grid), dim3(THREADS),
+                       0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
+                       g.tiles_per_block, b.counts, pp, id_bits);
+}
+
+// One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.  gen != nullptr: the
+// pass is the first one over freshly laid out rows -- its histogram kernel builds the sort words
+// (into b.comp[cur]) and its row ids are the positions.  pack: 0 = words and row ids travel
+// separately, 1 / 2 = the words carry the row id in their low id_bits bits (see the kernel).
 template <int THREADS, int ITEMS, int NPAY, int BITS>
 static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                             const PayPtrs &pp, const GenArgs *gen, bool hist_done) {
+                             const PayPtrs &pp, const GenArgs *gen, bool hist_done, int pack, int id_bits) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   uint32_t mask = (1u << nbits) - 1;
+  const int shift = lo + (pack ? id_bits : 0);
   GenArgs none;
   memset(&none, 0, sizeof(none));
   if (!hist_done) {
     ProfScope ps(gen ? "radix_hist_kernel+words" : "radix_hist_kernel", st);
-    if (gen)
-      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, true>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
+    if (gen && gen->id_bits)
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 2>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
+    else if (gen)
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 1>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
     else
-      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, false>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, lo, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr);
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 0>), dim3(g.grid), dim3(THREADS), 0, st,
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr);
     TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid);
   }
   {
-    ProfScope ps(NPAY == 0 ? "radix_scatter_kernel" : "radix_scatter_kernel+payload", st);
-    if (gen)
-      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true>), dim3(g.grid), dim3(THREADS), 0,
-                         st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                         g.tiles_per_block, b.counts, pp);
+    ProfScope ps(NPAY == 0 ? (pack ? "radix_scatter_kernel+ids_in_words" : "radix_scatter_kernel")
+                           : "radix_scatter_kernel+payload", st);
+    const bool first = gen != nullptr;
+    if (pack == 2)
+      radix_scatter_launch<THREADS, ITEMS, NPAY, BITS, 2>(b, n, cur, shift, mask, nbits, st, pp, first, g, id_bits);
+    else if (pack == 1 && NPAY == 0)
+      radix_scatter_launch<THREADS, ITEMS, 0, BITS, 1>(b, n, cur, shift, mask, nbits, st, pp, first, g, id_bits);
     else
-      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, false>), dim3(g.grid), dim3(THREADS), 0,
-                         st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                         g.tiles_per_block, b.counts, pp);
+      radix_scatter_launch<THREADS, ITEMS, NPAY, BITS, 0>(b, n, cur, shift, mask, nbits, st, pp, first, g, 0);
   }
 }
 
 template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                           const PayPtrs &pp, const GenArgs *gen, bool hist_done) {
-  if (nbits <= 8) radix_one_pass_t<THREADS, ITEMS, NPAY, 8>(b, n, cur, lo, nbits, st, pp, gen, hist_done);
-  else radix_one_pass_t<THREADS, ITEMS, NPAY, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, gen, hist_done);
+                           const PayPtrs &pp, const GenArgs *gen, bool hist_done, int pack, int id_bits) {
+  if (nbits <= 8)
+    radix_one_pass_t<THREADS, ITEMS, NPAY, 8>(b, n, cur, lo, nbits, st, pp, gen, hist_done, pack, id_bits);
+  else
+    radix_one_pass_t<THREADS, ITEMS, NPAY, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, gen, hist_done, pack, id_bits);
 }
 
 // Stable LSD passes over bits [lo_bit, hi_bit) of the pairs in b.comp[0] / b.idx[0] -- or, with
@@ -677,11 +718,22 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
   int passes = (total + 7) / 8;
   if ((total + RS_MAX_BITS - 1) / RS_MAX_BITS < passes) passes = (total + RS_MAX_BITS - 1) / RS_MAX_BITS;
   int lo = lo_bit;
+  // Narrow sort words leave room for the row id below them: the passes then move one 8-byte
+  // stream, and the last pass hands out plain words and row ids again.  Only when the words are
+  // laid out here (gen), so that nobody else ever sees the packed form.
+  const int id_bits = bits_for((uint64_t)(n > 1 ? n - 1 : 1));
+  const bool packed = gen != nullptr && passes > 1 && hi_bit + id_bits <= 64;
+  GenArgs gen_packed;
+  if (packed) {
+    gen_packed = *gen;
+    gen_packed.id_bits = id_bits;
+  }
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly: the first (total % passes) digits are one bit wider
     int nbits = total / passes + (p < total % passes ? 1 : 0);
     bool last = p + 1 == passes;
-    const GenArgs *g = p == 0 ? gen : nullptr;
+    const GenArgs *g = p == 0 ? (packed ? &gen_packed : gen) : nullptr;
+    const int pack = packed ? (last ? 2 : 1) : 0;
     if (last && n_pay > 0) {
       for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
         PayPtrs pp;
@@ -689,11 +741,11 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
         pp.n = n_pay - c0 < kMaxPay ? n_pay - c0 : kMaxPay;
         for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
         // a replay for further columns reuses the offsets of the first launch
-        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, c0 > 0);
+        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, c0 > 0, pack, id_bits);
       }
       if (carried) *carried = true;
     } else {
-      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none, g, false);
+      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none, g, false, pack, id_bits);
     }
     lo += nbits;
     cur ^= 1;
