@@ -1,10 +1,12 @@
 // EMA: fixed-tap FIR over the previous rows of the same series.  Replaces the `window` Lag
 // frames and the running when/otherwise sum of python/tempo/tsdf.py:615-635.
 //
-// Rows are ordered as __baseWindow does (tsdf.py:563-572).  A block stages the sort words and
-// metric values of its 1024 rows plus a (taps - 1)-row halo in LDS; each row then walks back
-// through its taps while the key field still matches, adding w[k] * x in the reference's
-// left-to-right order (no fused multiply-add: the library is built with -ffp-contract=off).
+// Rows are ordered as __baseWindow does (tsdf.py:563-572).  A block stages the metric values
+// (NULL -> 0) and key ids of its 1024 rows plus a (taps - 1)-row halo in LDS and works out where
+// the series of every staged row starts.  A thread then owns four consecutive rows: one value
+// read from LDS serves a tap of each of them, and every row adds its w[k] * x terms in the
+// reference's order k = 0, 1, 2, ... (no fused multiply-add: the library is built with
+// -ffp-contract=off), stopping where its series starts -- lag() beyond that is NULL.
 #include <string.h>
 
 #include "common.h"
@@ -13,6 +15,7 @@ namespace tmp {
 
 constexpr int EM_ROWS = 1024;
 constexpr int EM_THREADS = 256;
+constexpr int EM_PER = EM_ROWS / EM_THREADS;  // rows per thread
 
 __global__ __launch_bounds__(EM_THREADS) void ema_kernel(const uint64_t *comp, const uint32_t *perm,
                                                          const double *xs, const double *x_orig,
@@ -20,46 +23,109 @@ __global__ __launch_bounds__(EM_THREADS) void ema_kernel(const uint64_t *comp, c
                                                          const double *weights, int32_t *out_perm,
                                                          double *out) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int wave_last[EM_THREADS / 64];
   const int halo = taps > 0 ? taps - 1 : 0;
-  uint64_t *cw = (uint64_t *)smem;                 // [halo + EM_ROWS]
-  double *xv = (double *)(cw + halo + EM_ROWS);    // [halo + EM_ROWS]
-  double *w = xv + halo + EM_ROWS;                 // [taps]
+  const int cap = halo + EM_ROWS;
+  double *xv = (double *)smem;            // [cap] metric, 0 for NULL
+  double *w = xv + cap;                   // [taps]
+  int *st = (int *)(w + (taps > 0 ? taps : 1));  // [cap] key id, then: first slot of the row's series
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t t0 = (int64_t)blockIdx.x * EM_ROWS;
   const int64_t t1 = t0 + EM_ROWS < n ? t0 + EM_ROWS : n;
   const int64_t h0 = t0 - halo;  // may be negative
   const int total = (int)(t1 - h0);
-  for (int e = threadIdx.x; e < total; e += EM_THREADS) {
-    int64_t j = h0 + e;
-    uint64_t c = 0;
-    double v = 0.0;
-    if (j >= 0) {
-      c = comp[j];
-      if (c & 1ull) v = xs ? xs[j] : x_orig[perm[j]];
-    }
-    cw[e] = c;
-    xv[e] = v;
-  }
-  for (int k = threadIdx.x; k < taps; k += EM_THREADS) w[k] = weights[k];
-  __syncthreads();
   const int ks = lay.key_shift();
   const bool has_key = lay.key_bits > 0;
-  for (int64_t i = t0 + threadIdx.x; i < t1; i += EM_THREADS) {
-    int e = (int)(i - h0);
-    uint64_t ci = cw[e];
-    uint64_t key_i = has_key ? (ci >> ks) : 0;
-    double acc = 0.0;
-    for (int k = 0; k < taps; ++k) {
-      int64_t j = i - k;
-      if (j < 0) break;
-      uint64_t cj = cw[e - k];
-      if (has_key && (cj >> ks) != key_i) break;  // lag() beyond the series start is NULL
-      if (cj & 1ull) {
-        double t = w[k] * xv[e - k];
-        acc = acc + t;
+  for (int e = tid; e < total; e += EM_THREADS) {
+    int64_t j = h0 + e;
+    double v = 0.0;
+    int kid = -1;  // rows before the table: a series of their own
+    if (j >= 0) {
+      uint64_t c = comp[j];
+      kid = has_key ? (int)(uint32_t)(c >> ks) : 0;
+      if (c & 1ull) v = xs ? xs[j] : x_orig[perm[j]];
+    }
+    xv[e] = v;
+    st[e] = kid;
+  }
+  for (int k = tid; k < taps; k += EM_THREADS) w[k] = weights[k];
+  __syncthreads();
+
+  // ---- first slot of every slot's series: a running maximum over "a series starts here" marks.
+  //      Thread t owns the slots [t * per, (t + 1) * per); slot 0 counts as a start (a series that
+  //      began before the halo is at least `taps` rows long for every row of the tile).
+  const int per = (total + EM_THREADS - 1) / EM_THREADS;
+  const int lo = tid * per, hi = lo + per < total ? lo + per : total;
+  int prev = lo > 0 && lo <= total ? st[lo - 1] : -2;
+  int last = -1;  // last start at or before the slot, inside this thread's range
+  {
+    int p = prev;
+    for (int e = lo; e < hi; ++e) {
+      const int kid = st[e];
+      if (e == 0 || kid != p) last = e;
+      p = kid;
+    }
+  }
+  int inc = last;
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o && t > inc) inc = t;
+  }
+  if (lane == 63) wave_last[wave] = inc;
+  int carry = __shfl_up(inc, 1, 64);
+  if (lane == 0) carry = -1;
+  __syncthreads();  // every thread has read the key ids it needs; st is rewritten below
+  for (int wv = 0; wv < wave; ++wv) carry = carry > wave_last[wv] ? carry : wave_last[wv];
+  {
+    int p = prev, run = carry;
+    // second sweep over the same slots: key ids are still in place for this thread's own range
+    for (int e = lo; e < hi; ++e) {
+      const int kid = st[e];
+      if (e == 0 || kid != p) run = e;
+      p = kid;
+      st[e] = run;
+    }
+  }
+  __syncthreads();
+
+  // ---- four consecutive rows per thread
+  const int e0 = halo + tid * EM_PER;
+  const int64_t i0 = t0 + (int64_t)tid * EM_PER;
+  if (i0 >= t1) return;
+  int m[EM_PER];
+  double acc[EM_PER];
+#pragma unroll
+  for (int r = 0; r < EM_PER; ++r) {
+    const int e = e0 + r;
+    int len = e < total ? e - st[e] + 1 : 0;  // rows of the series up to and including this one
+    m[r] = len < taps ? len : taps;
+    acc[r] = 0.0;
+  }
+  for (int d = -(EM_PER - 1); d < taps; ++d) {
+    const int at = e0 - d;
+    const double x = at < total ? xv[at] : 0.0;
+#pragma unroll
+    for (int r = 0; r < EM_PER; ++r) {
+      const int k = d + r;  // uniform over the block
+      if (k >= 0 && k < taps) {
+        const double t = w[k] * x;
+        if (k < m[r]) acc[r] = acc[r] + t;
       }
     }
-    out[i] = acc;
-    out_perm[i] = (int32_t)perm[i];
+  }
+  const bool vec = i0 + EM_PER <= t1 && (((uintptr_t)out | (uintptr_t)out_perm) & 15) == 0;
+  if (vec) {
+    *reinterpret_cast<double2 *>(out + i0) = make_double2(acc[0], acc[1]);
+    *reinterpret_cast<double2 *>(out + i0 + 2) = make_double2(acc[2], acc[3]);
+    const uint4 pv = *reinterpret_cast<const uint4 *>(perm + i0);
+    *reinterpret_cast<uint4 *>(out_perm + i0) = pv;
+  } else {
+#pragma unroll
+    for (int r = 0; r < EM_PER; ++r)
+      if (i0 + r < t1) {
+        out[i0 + r] = acc[r];
+        out_perm[i0 + r] = (int32_t)perm[i0 + r];
+      }
   }
 }
 
@@ -122,7 +188,7 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   int taps = a->n_taps;  // zero taps: the column stays lit(0)
   if (taps > 0)
     TMP_CHECK_HIP(hipMemcpyAsync(p.w, a->weights, sizeof(double) * taps, hipMemcpyHostToDevice, st));
-  size_t shm = (size_t)((taps > 0 ? taps - 1 : 0) + EM_ROWS) * 16 + (size_t)(taps > 0 ? taps : 1) * 8;
+  size_t shm = (size_t)((taps > 0 ? taps - 1 : 0) + EM_ROWS) * 12 + (size_t)(taps > 0 ? taps : 1) * 8;
   int grid = (int)((a->n + EM_ROWS - 1) / EM_ROWS);
   {
     ProfScope ps("ema_kernel", st);
