@@ -129,8 +129,9 @@ struct FeatPtrs {
   const uint8_t *v[TMP_MAX_FEATURES];
 };
 
-// One thread per output element; element e = (o * L + l) * F + f.
-__global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
+// One thread per output element; element e = (o * L + l) * F + f.  General form (64-bit index
+// arithmetic per element): used when a row's L * F elements are too many for the blocked form.
+__global__ __launch_bounds__(LB_THREADS) void lookback_write_wide_kernel(
     const uint32_t *row_pos, const uint32_t *perm, const int32_t *len32, const int64_t *count,
     int lookback, int n_feat, int exact, FeatPtrs fp, double *out, uint8_t *out_valid) {
   const int64_t per_row = (int64_t)lookback * n_feat;
@@ -151,6 +152,102 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
     }
     out[e] = val;
     if (out_valid) out_valid[e] = ok;
+  }
+}
+
+// Blocked form: a block owns 256 output rows, keeps their positions and history lengths in LDS
+// and walks their L * F elements in output order (stores coalesce); the element -> (row, l, f)
+// split is 32-bit arithmetic with float reciprocals, exact after one correction step because
+// every index stays below 2^22.
+constexpr int LBW_ROWS = 256;
+constexpr uint32_t LBW_MAX_PER_ROW = 16384;
+
+__device__ __forceinline__ uint32_t div_small(uint32_t q, uint32_t d, float inv, uint32_t *rem) {
+  uint32_t o = (uint32_t)((float)q * inv);
+  int32_t r = (int32_t)(q - o * d);
+  if (r < 0) { --o; r += (int32_t)d; }
+  else if (r >= (int32_t)d) { ++o; r -= (int32_t)d; }
+  *rem = (uint32_t)r;
+  return o;
+}
+
+__global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
+    const uint32_t *row_pos, const uint32_t *perm, const int32_t *len32, const int64_t *count,
+    int lookback, int n_feat, int exact, FeatPtrs fp, double *out, uint8_t *out_valid,
+    float inv_per_row, float inv_feat, int cap) {
+  extern __shared__ __align__(16) unsigned char lb_smem[];
+  __shared__ uint32_t pos_s[LBW_ROWS];
+  __shared__ int m_s[LBW_ROWS];
+  const int64_t n_out = *count;
+  const int64_t o0 = (int64_t)blockIdx.x * LBW_ROWS;
+  if (o0 >= n_out) return;
+  const int rows = (int)(n_out - o0 < LBW_ROWS ? n_out - o0 : LBW_ROWS);
+  for (int t = threadIdx.x; t < rows; t += LB_THREADS) {
+    const uint32_t p = row_pos[o0 + t];
+    pos_s[t] = p;
+    m_s[t] = exact ? lookback : len32[p];
+  }
+  __syncthreads();
+  // The histories of the block's rows are one stretch of the ordered table (a history starts no
+  // earlier than the one before it): when it fits, its feature values are brought into LDS once,
+  // each through one read of the row id, instead of once per output element.
+  const uint32_t first = pos_s[0] - (uint32_t)m_s[0];
+  const uint32_t span = pos_s[rows - 1] - first;  // slots first .. pos - 1 of the last row
+  const bool staged = cap > 0 && span <= (uint32_t)cap;
+  double *xv = (double *)lb_smem;                      // [n_feat][cap]
+  uint8_t *okv = lb_smem + (size_t)cap * n_feat * 8;   // [n_feat][cap]
+  if (staged) {
+    for (uint32_t sl = threadIdx.x; sl < span; sl += LB_THREADS) {
+      const uint32_t src = perm[first + sl];
+      for (int f = 0; f < n_feat; ++f) {
+        const uint8_t ok = fp.v[f] ? fp.v[f][src] : 1;
+        okv[(size_t)f * cap + sl] = ok;
+        xv[(size_t)f * cap + sl] = ok ? fp.x[f][src] : 0.0;
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t per_row = (uint32_t)lookback * (uint32_t)n_feat;
+  const uint32_t total = (uint32_t)rows * per_row;
+  double *ob = out + o0 * per_row;
+  uint8_t *vb = out_valid ? out_valid + o0 * per_row : nullptr;
+  auto element = [&](uint32_t q, double &val, uint8_t &ok) {
+    uint32_t rem, f;
+    const uint32_t o = div_small(q, per_row, inv_per_row, &rem);
+    const uint32_t l = div_small(rem, (uint32_t)n_feat, inv_feat, &f);
+    const int m = m_s[o];
+    val = 0.0;
+    ok = 0;
+    if ((int)l < m) {
+      const uint32_t at = pos_s[o] - (uint32_t)m + l;
+      if (staged) {
+        ok = okv[(size_t)f * cap + (at - first)];
+        val = xv[(size_t)f * cap + (at - first)];
+      } else {
+        const uint32_t src = perm[at];
+        ok = fp.v[f] ? fp.v[f][src] : 1;
+        val = ok ? fp.x[f][src] : 0.0;
+      }
+    }
+  };
+  // two elements per thread and step, stored as one 16-byte word where the output allows it
+  const bool wide = (((uintptr_t)ob) & 15) == 0;
+  for (uint32_t q = threadIdx.x * 2; q < total; q += LB_THREADS * 2) {
+    double v0, v1 = 0.0;
+    uint8_t k0, k1 = 0;
+    element(q, v0, k0);
+    const bool two = q + 1 < total;
+    if (two) element(q + 1, v1, k1);
+    if (two && wide) {
+      *reinterpret_cast<double2 *>(ob + q) = make_double2(v0, v1);
+    } else {
+      ob[q] = v0;
+      if (two) ob[q + 1] = v1;
+    }
+    if (vb) {
+      vb[q] = k0;
+      if (two) vb[q + 1] = k1;
+    }
   }
 }
 
@@ -223,9 +320,23 @@ extern "C" int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t 
   TMP_LAUNCH(lookback_slots_kernel, dim3(p.nblocks), dim3(LB_THREADS), st, res.comp, res.perm, a->n, exact,
              p.full, p.block_counts, p.row_pos, a->out_rows);
   int64_t max_elems = a->n * (int64_t)a->lookback * a->n_feat;
-  TMP_LAUNCH(lookback_write_kernel, dim3(grid_for(max_elems, LB_THREADS * 8, 1 << 16)), dim3(LB_THREADS), st,
-             p.row_pos, res.perm, a->out_len, a->out_count, a->lookback, a->n_feat, exact, fp, a->out_feat,
-             a->out_feat_valid);
+  const int64_t per_row = (int64_t)a->lookback * a->n_feat;
+  if (per_row <= (int64_t)LBW_MAX_PER_ROW) {
+    // LDS room for the staged histories: 9 bytes per slot and feature, at most ~60 KB; pointless
+    // when it cannot even hold one row's history plus a few rows
+    int cap = 61440 / (9 * a->n_feat);
+    cap = cap > 4096 ? 4096 : cap / 16 * 16;
+    if (cap < a->lookback + 64) cap = 0;
+    ProfScope ps("lookback_write_kernel", st);
+    hipLaunchKernelGGL(lookback_write_kernel, dim3((unsigned)((a->n + LBW_ROWS - 1) / LBW_ROWS)), dim3(LB_THREADS),
+                       (size_t)cap * a->n_feat * 9, st, p.row_pos, res.perm, a->out_len, a->out_count, a->lookback,
+                       a->n_feat, exact, fp, a->out_feat, a->out_feat_valid, 1.0f / (float)per_row,
+                       1.0f / (float)a->n_feat, cap);
+  }
+  else
+    TMP_LAUNCH(lookback_write_wide_kernel, dim3(grid_for(max_elems, LB_THREADS * 8, 1 << 16)), dim3(LB_THREADS), st,
+               p.row_pos, res.perm, a->out_len, a->out_count, a->lookback, a->n_feat, exact, fp, a->out_feat,
+               a->out_feat_valid);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

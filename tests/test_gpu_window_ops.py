@@ -337,3 +337,19 @@ def test_grouped_stats_big_buckets(orc, ops):
         np.testing.assert_allclose(r["stddev"][c].cpu().numpy(), e["stddev"][c], rtol=1e-9)
     assert np.array_equal(r["sum"][1].cpu().numpy(), e["sum"][1])
     np.testing.assert_allclose(r["sum"][0].cpu().numpy(), e["sum"][0], rtol=1e-9)
+
+
+def test_lookback_very_long_history(orc, ops):
+    """L * F beyond the blocked writer's range (16384 elements per row): the general writer."""
+    rng = np.random.default_rng(77)
+    n, L = 3000, 5600
+    key = np.zeros(n, np.int32)
+    ts = BASE + np.arange(n) * 1_000_000
+    xs = [rng.normal(0, 1, n), rng.normal(5, 2, n), rng.normal(1, 1, n)]
+    xv = [None, (rng.random(n) >= 0.2).astype(np.uint8), None]
+    rows, lens, feat, fv = ops.lookback(_dev(key), _dev(ts), [_dev(x) for x in xs], [_dev(v) for v in xv], 1, L,
+                                        exact_size=False)
+    operm, olen, ofeat, ofv = orc.lookback(key, ts, xs, xv, L)
+    assert np.array_equal(rows.cpu().numpy().astype(np.int64), operm)
+    assert np.array_equal(lens.cpu().numpy(), olen)
+    assert np.array_equal(feat.cpu().numpy(), ofeat) and np.array_equal(fv.cpu().numpy(), ofv)
