@@ -16,12 +16,18 @@ constexpr int RB_THREADS = 256;
 constexpr int BB_TILE = 4096;       // rows per tile of the big-bucket path
 constexpr int64_t BB_BIG = 32768;   // buckets longer than this are cut into tiles
 
+// Bucket index of an order key.  dur == 1: the rows were ordered by the bucket index itself
+// (operators that do not care about the order inside a bucket), the key is the index.
+__device__ __forceinline__ int64_t bucket_index(int64_t prim, int64_t dur) {
+  return dur == 1 ? prim : floordiv_i64(prim, dur);
+}
+
 __device__ __forceinline__ bool bucket_head(const uint64_t *comp, int64_t i, const Layout &lay,
                                             int64_t dur) {
   if (i == 0) return true;
   uint64_t a = comp[i - 1], b = comp[i];
   if (lay.key_of(a) != lay.key_of(b)) return true;
-  return floordiv_i64(lay.prim_of(a), dur) != floordiv_i64(lay.prim_of(b), dur);
+  return bucket_index(lay.prim_of(a), dur) != bucket_index(lay.prim_of(b), dur);
 }
 
 __global__ __launch_bounds__(RB_THREADS) void bucket_count_kernel(const uint64_t *comp, int64_t n,
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(1024) void bucket_offsets_kernel(uint32_t *block_co
 }
 
 __global__ __launch_bounds__(RB_THREADS) void bucket_starts_kernel(const uint64_t *comp, int64_t n,
-                                                                   Layout lay, int64_t dur,
+                                                                   Layout lay, int64_t dur, int64_t unit,
                                                                    const uint32_t *block_offsets,
                                                                    uint32_t *bstart, int32_t *out_key,
                                                                    int64_t *out_start) {
@@ -105,7 +111,8 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_starts_kernel(const uint64_
       bstart[b] = (uint32_t)i;
       uint64_t c = comp[i];
       out_key[b] = (int32_t)lay.key_of(c);
-      out_start[b] = floordiv_i64(lay.prim_of(c), dur) * dur;  // ts - ((ts mod dur) + dur) mod dur
+      // ts - ((ts mod dur) + dur) mod dur, in the timestamp's unit
+      out_start[b] = bucket_index(lay.prim_of(c), dur) * dur * unit;
     }
     base += tot;
     __syncthreads();
@@ -179,17 +186,31 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_pick_kernel(const uint64_t 
 }
 
 // mean / min / max: one wave per bucket and column.
+// Order in which the waves take the buckets.  Buckets are numbered key by key, but the rows of a
+// time-ordered feed lie time by time: waves that run side by side should work on the same stretch
+// of time for all keys, so that the sectors they gather from are fetched once for all of them.
+// Work item j goes to bucket (j mod K) * per + j / K (per = ceil(nb / K), K = number of keys): a
+// permutation of [0, K * per) whose items beyond nb are skipped -- exact interleaving when every
+// key has the same number of buckets, merely a different order otherwise.
+__device__ __forceinline__ int64_t work_bucket(int64_t j, int64_t nb, int64_t n_keys, int64_t per) {
+  const int64_t b = (j % n_keys) * per + j / n_keys;
+  return b < nb ? b : -1;
+}
+
 __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_t *perm,
                                                                    const uint32_t *bstart,
                                                                    const int64_t *count, int func,
                                                                    int n_cols, ColPtrs cols,
                                                                    int64_t cap, double *out_f64,
                                                                    int64_t *out_i64,
-                                                                   uint8_t *out_valid) {
+                                                                   uint8_t *out_valid, int64_t n_keys) {
   const int64_t nb = *count;
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
+  const int64_t per = (nb + n_keys - 1) / n_keys;
+  for (int64_t j = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); j < per * n_keys; j += waves) {
+    const int64_t b = work_bucket(j, nb, n_keys, per);
+    if (b < 0) continue;
     int64_t lo = bstart[b], hi = bstart[b + 1];
     if (hi - lo > BB_BIG) continue;  // cut into tiles by the big-bucket kernels
     for (int k = 0; k < n_cols; ++k) {
@@ -358,12 +379,15 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_big_tiles_kernel(const uint
                                                                       const uint32_t *bstart,
                                                                       const int64_t *count, int64_t n,
                                                                       int n_cols, ColPtrs cols,
-                                                                      BigAgg *part) {
+                                                                      BigAgg *part, int64_t n_keys) {
   const int64_t nb = *count;
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int64_t tiles = (n + BB_TILE - 1) / BB_TILE;
-  for (int64_t t = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); t < tiles; t += waves) {
+  const int64_t per = (tiles + n_keys - 1) / n_keys;  // tiles are taken key-interleaved, like buckets
+  for (int64_t j = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); j < per * n_keys; j += waves) {
+    const int64_t t = work_bucket(j, tiles, n_keys, per);
+    if (t < 0) continue;
     const int64_t r0 = t * BB_TILE, r1 = r0 + BB_TILE < n ? r0 + BB_TILE : n;
     for (int slot = 0; slot < 2; ++slot) {
       const int64_t row = slot == 0 ? r0 : r1 - 1;
@@ -461,11 +485,14 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t
                                                                   const uint32_t *bstart,
                                                                   const int64_t *count, int n_cols,
                                                                   ColPtrs cols, int64_t cap,
-                                                                  StatsOut o) {
+                                                                  StatsOut o, int64_t n_keys) {
   const int64_t nb = *count;
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t b = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); b < nb; b += waves) {
+  const int64_t per = (nb + n_keys - 1) / n_keys;
+  for (int64_t j = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6); j < per * n_keys; j += waves) {
+    const int64_t b = work_bucket(j, nb, n_keys, per);
+    if (b < 0) continue;
     const int64_t lo = bstart[b], hi = bstart[b + 1];
     if (hi - lo > BB_BIG) continue;  // cut into tiles by the big-bucket kernels
     for (int k = 0; k < n_cols; ++k) {
@@ -646,7 +673,12 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
-  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1; s.coarse_ok = 1;
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.coarse_ok = 1;
+  // min / max / mean do not depend on the order inside a bucket: the rows are ordered by
+  // (key, bucket index) only -- far fewer bits to sort, and a feed that is in time order up to
+  // jitter inside a bucket needs passes over the key bits alone.  floor / ceil keep the order by ts.
+  const int64_t dur = reduce ? 1 : a->dur_us, unit = reduce ? a->dur_us : 1;
+  s.prim_div = reduce ? a->dur_us : 1;
   Layout lay;
   OrderResult res;
   TMP_TRY(order_single(s, p.ob, &lay, &res, st));
@@ -658,19 +690,21 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     cp.valid[k] = a->col_valid[k];
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
-  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, dur,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
              p.bstart, a->n);
-  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, dur, unit,
              p.block_counts, p.bstart, a->out_key, a->out_start);
   if (reduce) {
     if (a->n_cols > 0) {
       TMP_LAUNCH(bucket_reduce_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
-                 p.bstart, a->out_count, a->func, a->n_cols, cp, a->n, a->out_f64, a->out_i64, a->out_valid);
+                 p.bstart, a->out_count, a->func, a->n_cols, cp, a->n, a->out_f64, a->out_i64, a->out_valid,
+                 (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
       if (a->n > BB_BIG) {  // only then can a bucket be a big one
         TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
-                   dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part);
+                   dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
+                   (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
         TMP_LAUNCH(bucket_big_reduce_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
                    dim3(RB_THREADS), st, p.bstart, a->out_count, a->func, a->n_cols, cp, p.part, a->n,
                    a->out_f64, a->out_i64, a->out_valid);
@@ -715,7 +749,8 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
-  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.prim_div = 1; s.coarse_ok = 1;
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts; s.coarse_ok = 1;
+  s.prim_div = a->dur_us;  // ordered by (key, bucket index): the statistics ignore the order inside a bucket
   Layout lay;
   OrderResult res;
   TMP_TRY(order_single(s, p.ob, &lay, &res, st));
@@ -727,21 +762,22 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     cp.valid[k] = a->col_valid[k];
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
-  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
+  TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, (int64_t)1,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
              p.bstart, a->n);
-  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, a->dur_us,
-             p.block_counts, p.bstart, a->out_key, a->out_start);
+  TMP_LAUNCH(bucket_starts_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, (int64_t)1,
+             a->dur_us, p.block_counts, p.bstart, a->out_key, a->out_start);
   if (a->n_cols > 0) {
     StatsOut o;
     o.mean = a->out_mean; o.n = a->out_n; o.mn = (uint64_t *)a->out_min; o.mx = (uint64_t *)a->out_max;
     o.sum = (uint64_t *)a->out_sum; o.stddev = a->out_stddev;
     TMP_LAUNCH(bucket_stats_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
-               p.bstart, a->out_count, a->n_cols, cp, a->n, o);
+               p.bstart, a->out_count, a->n_cols, cp, a->n, o, (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
     if (a->n > BB_BIG) {
       TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
-                 dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part);
+                 dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
+                   (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
       TMP_LAUNCH(bucket_big_stats_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
                  dim3(RB_THREADS), st, p.bstart, a->out_count, a->n_cols, cp, p.part, a->n, o);
     }
