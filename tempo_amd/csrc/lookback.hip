@@ -327,6 +327,10 @@ extern "C" int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t 
     int cap = 61440 / (9 * a->n_feat);
     cap = cap > 4096 ? 4096 : cap / 16 * 16;
     if (cap < a->lookback + 64) cap = 0;
+    // no more than a block of dense rows needs (256 rows + one history + slack): the smaller the
+    // staging area, the more blocks a CU holds
+    const int want = (a->lookback + LBW_ROWS + 128 + 15) / 16 * 16;
+    if (cap > want) cap = want;
     ProfScope ps("lookback_write_kernel", st);
     hipLaunchKernelGGL(lookback_write_kernel, dim3((unsigned)((a->n + LBW_ROWS - 1) / LBW_ROWS)), dim3(LB_THREADS),
                        (size_t)cap * a->n_feat * 9, st, p.row_pos, res.perm, a->out_len, a->out_count, a->lookback,
