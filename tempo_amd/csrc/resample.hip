@@ -185,7 +185,6 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_pick_kernel(const uint64_t 
   }
 }
 
-// mean / min / max: one wave per bucket and column.
 // Order in which the waves take the buckets.  Buckets are numbered key by key, but the rows of a
 // time-ordered feed lie time by time: waves that run side by side should work on the same stretch
 // of time for all keys, so that the sectors they gather from are fetched once for all of them.
@@ -197,6 +196,7 @@ __device__ __forceinline__ int64_t work_bucket(int64_t j, int64_t nb, int64_t n_
   return b < nb ? b : -1;
 }
 
+// mean / min / max: one wave per bucket and column.
 __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_t *perm,
                                                                    const uint32_t *bstart,
                                                                    const int64_t *count, int func,
