@@ -21,10 +21,42 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process
+    (torch.distributed.run), relay rank 0's JSON line and leave with the child's exit status.
+    Nothing in this parent has touched the GPU yet, and the parent never replaces itself."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    sys.stdout.buffer.write(proc.stdout)
+    sys.stdout.flush()
+    sys.exit(proc.returncode)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _requested_gpus(sys.argv[1:]) > 1:
+    _launch_ranks(_requested_gpus(sys.argv[1:]))
+
+import torch  # noqa: E402
 
 from tempo_amd import _lib, ops  # noqa: E402
 
@@ -120,6 +152,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per operator per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-shuffled", action="store_true",
+                    help="skip the extra withRangeStats run on a row-permuted tick table")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: native libraries that print banners to file
@@ -133,7 +167,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            sys.exit("bench.py --gpus N>1: WORLD_SIZE=1 in the environment; unset it (bench.py then starts "
+                     "its own ranks) or launch with torch.distributed.run")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
@@ -239,13 +274,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rows_per_rank = [[n1[0], n1[1], n2]]
+    rccl_ranks = 1
     if dist:
+        rccl_ranks = dist.get_world_size() if dist.get_backend() == "nccl" else 0
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # what the ranks held after the last step's shuffle: every trade and tick exactly once,
         # every quote once plus the few carried across a time-slice boundary
         r = torch.tensor([n1[0], n1[1], n2], dtype=torch.int64, device=dev)
+        per_rank = torch.zeros((world, 3), dtype=torch.int64, device=dev)
+        per_rank[rank] = r
+        all_reduce(per_rank, dist.ReduceOp.SUM)
+        rows_per_rank = [[int(v) for v in row] for row in per_rank.tolist()]
         all_reduce(r, dist.ReduceOp.SUM)
         held = [int(v) for v in r.tolist()]
         if held[0] != world * n_left or held[2] != world * rows or not (
@@ -293,6 +335,23 @@ def main():
             roofline = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=None, traffic=None)
 
+    # ---- the same withRangeStats on a row-permuted copy of the tick table (not part of `value`):
+    # what the operator costs when the feed is not time-ordered -- the full (key, second) sort
+    shuffled_ms = None
+    if rank == 0 and args.gpus == 1 and not args.no_shuffled:
+        torch.cuda.synchronize()
+        p = torch.randperm(rows, device=dev)
+        ts_p = {k: v[p] for k, v in tk.items()}
+        del p
+        ops.range_stats(ts_p["key"], ts_p["ts"], ts_p["x"], ts_p["x_valid"], TICK_KEYS, 600)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ops.range_stats(ts_p["key"], ts_p["ts"], ts_p["x"], ts_p["x_valid"], TICK_KEYS, 600)
+        torch.cuda.synchronize()
+        shuffled_ms = (time.perf_counter() - t1) / 2 * 1e3
+        del ts_p
+
     # ---- CPU baseline: the C oracle (a port of the reference plan) on a bounded sample, 1 core
     cpu = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
@@ -305,10 +364,20 @@ def main():
         # input read once, every output written once, no sort pass or scratch credited --
         # asofJoin: 12 B key/ts per row of both sides + 3 joined 8-byte columns read and written;
         # withRangeStats: 12 B key/ts + 8 B metric read, 7 x 8 B written
-        step_bytes = world * ((n_left + n_right) * 12 + (n_left + n_right) * 24 + rows * (12 + 8 + 56))
+        asof_bytes = (n_left + n_right) * 12 + n_right * 24 + n_left * 24
+        stats_bytes = rows * (12 + 8 + 56)
+        step_bytes = world * (asof_bytes + stats_bytes)
         if roofline is not None:
             roofline["step_algorithmic_bytes"] = step_bytes
             roofline["step_frac_of_peak"] = round(step_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
+            # per operator: compulsory bytes / device time of the operator's kernels (rank 0) / peak
+            per_op = {}
+            for name, tag, nbytes in (("asofJoin", 1, asof_bytes), ("withRangeStats", 2, stats_bytes)):
+                ms = op_ms.get(tag, 0.0) / args.steps
+                if ms > 0:
+                    per_op[name] = dict(bytes=nbytes, ms=round(ms, 3),
+                                        frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            roofline["ops"] = per_op
         top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:8]
         line = {
             "metric": "AS-OF join + withRangeStats rows/sec at 1B rows (1-8 GPU); % HBM peak",
@@ -318,10 +387,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("asofJoin %d trades x %d quotes per GPU (10k Zipf(1.2) symbols, "
-                             "tsPartitionVal=10, fraction=0.1, 3 joined cols) + "
-                             "withRangeStats(600 s) on %d ticks per GPU (100 symbols)"
-                             % (n_left, n_right, rows)),
+                             "rows in random order, tsPartitionVal=10, fraction=0.1, 3 joined cols) + "
+                             "withRangeStats(600 s) on %d ticks per GPU (100 symbols, time-ordered rows "
+                             "with interleaved keys)" % (n_left, n_right, rows)),
                 "rows_per_gpu_per_op": rows,
+                "rccl_ranks": rccl_ranks,
+                "rows_held_per_rank": rows_per_rank,
+                "range_stats_shuffled_ms_per_step": None if shuffled_ms is None else round(shuffled_ms, 3),
                 "peak_hbm_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),

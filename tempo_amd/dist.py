@@ -190,32 +190,52 @@ def _counts_all_to_all(recv, send, group):
         dist.all_to_all_single(recv, send, group=group)
 
 
+def _offsets(lens):
+    off = [0]
+    for v in lens[:-1]:
+        off.append(off[-1] + v)
+    return off
+
+
+def _round_views(buf, off, lens, lo, hi):
+    """Per peer, the rows [lo, hi) of that peer's segment of `buf` (segments start at off[r] and
+    hold lens[r] rows; a segment shorter than `lo` contributes an empty view)."""
+    return [buf[off[r] + min(lo, lens[r]): off[r] + min(hi, lens[r])] for r in range(len(lens))]
+
+
 def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
     """All-to-all of one column in `rounds` slices: round c moves rows [c*R, (c+1)*R) of what
-    every rank sends to every other rank.  Views only, nothing is copied.  Returns the pending
-    work handles (the collectives are issued asynchronously, in order)."""
+    every rank sends to every other rank.  Returns the pending work handles (the collectives
+    are issued asynchronously, in order).
+
+    RCCL: per round one grouped send/recv over views of the two buffers, nothing is copied.
+    gloo (tests and rehearsals; it has no list all-to-all): the round's views are gathered into
+    one contiguous message for all_to_all_single and the answer is copied out again; device
+    tensors are staged through host memory first."""
     if _host_staged(group, staged):
         h_got = torch.empty(got.shape, dtype=got.dtype)
-        dist.all_to_all_single(h_got, staged.cpu(), output_split_sizes=recv_l, input_split_sizes=send_l, group=group)
+        _exchange(staged.cpu(), h_got, send_l, recv_l, rounds, rows_per_round, group)
         got.copy_(h_got)
         return []
-    s_off = [0]
-    for v in send_l[:-1]:
-        s_off.append(s_off[-1] + v)
-    r_off = [0]
-    for v in recv_l[:-1]:
-        r_off.append(r_off[-1] + v)
     if rounds == 1:
         return [dist.all_to_all_single(got, staged, output_split_sizes=recv_l, input_split_sizes=send_l,
                                        group=group, async_op=True)]
+    s_off, r_off = _offsets(send_l), _offsets(recv_l)
     works = []
     for c in range(rounds):
-        lo = c * rows_per_round
-        ins = [staged[s_off[r] + min(lo, send_l[r]): s_off[r] + min(lo + rows_per_round, send_l[r])]
-               for r in range(len(send_l))]
-        outs = [got[r_off[r] + min(lo, recv_l[r]): r_off[r] + min(lo + rows_per_round, recv_l[r])]
-                for r in range(len(recv_l))]
-        works.append(dist.all_to_all(outs, ins, group=group, async_op=True))
+        lo, hi = c * rows_per_round, (c + 1) * rows_per_round
+        ins = _round_views(staged, s_off, send_l, lo, hi)
+        outs = _round_views(got, r_off, recv_l, lo, hi)
+        if dist.get_backend(group) == "gloo":
+            msg = torch.empty(sum(o.numel() for o in outs), dtype=got.dtype)
+            dist.all_to_all_single(msg, torch.cat(ins), output_split_sizes=[o.numel() for o in outs],
+                                   input_split_sizes=[i.numel() for i in ins], group=group)
+            at = 0
+            for o in outs:
+                o.copy_(msg[at:at + o.numel()])
+                at += o.numel()
+        else:
+            works.append(dist.all_to_all(outs, ins, group=group, async_op=True))
     return works
 
 

@@ -59,6 +59,9 @@ def join_scenario(out_dir, rank, world):
 
 def main():
     out_dir = sys.argv[1]
+    if os.environ.get("TEMPO_TEST_MAX_MESSAGE_BYTES"):  # force the exchange into many small rounds
+        import tempo_amd.dist as tdist
+        tdist.MAX_MESSAGE_BYTES = int(os.environ["TEMPO_TEST_MAX_MESSAGE_BYTES"])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     rng = np.random.default_rng(1234)  # every rank draws the same global table and keeps its slice

@@ -9,8 +9,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_key_shuffle_two_ranks(tmp_path, orc):
+import pytest
+
+
+@pytest.mark.parametrize("max_message_bytes", [None, 1000])
+def test_key_shuffle_two_ranks(tmp_path, orc, max_message_bytes):
+    """max_message_bytes=1000: every column goes out in many rounds (125 rows of an 8-byte
+    column per peer and round), the path a 10^9-row column takes at the default 1 GiB limit."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    if max_message_bytes:
+        env["TEMPO_TEST_MAX_MESSAGE_BYTES"] = str(max_message_bytes)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)

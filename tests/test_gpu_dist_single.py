@@ -189,6 +189,52 @@ def test_shuffle_with_sliced_plan_single_rank_nccl():
             dist.destroy_process_group()
 
 
+def test_chunked_exchange_equals_single_message(monkeypatch):
+    """Columns larger than MAX_MESSAGE_BYTES go out as a sequence of grouped send/recv rounds over
+    views (what every 10^9-row column does under RCCL).  With the limit at 64 KiB a 200k-row
+    table needs up to 25 rounds; every column (1-, 4- and 8-byte elements, plus the empty halo
+    route of a sliced plan) must arrive exactly as through one all_to_all_single."""
+    import torch.distributed as dist
+    import tempo_amd.dist as tdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29579")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(9)
+        n = 200_003
+        kl, tl, kr, tr = _skew_tables(rng, n, 20, 0.5)
+        x = rng.normal(0, 1, n)
+        flag = (rng.random(n) > 0.5).astype(np.uint8)
+        small = rng.integers(-9, 9, n).astype(np.int32)
+        d = lambda a: torch.from_numpy(a).cuda()
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device="cuda")
+        table = torch.zeros(20, dtype=torch.int32, device="cuda")
+        table[0] = -1
+        plan = tdist.OwnerPlan(table, dict(ts_partition_val=10.0, v_is_int=True, ts_is_seconds=False,
+                                           one_minus_fraction=0.9, bracket_min=int(tr.min() // 10_000_000),
+                                           bracket_count=361, split_slices=i32([4]), split_first=i32([0]),
+                                           slice_owner=i32([0, 0, 0, 0])))
+        cols = [d(tr), d(x), d(flag), d(small)]
+        whole = tdist.shuffle_by_key(d(kr), cols, owners=plan, ts=cols[0], halo=True)
+        monkeypatch.setattr(tdist, "MAX_MESSAGE_BYTES", 1 << 16)
+        calls = []
+        real = dist.all_to_all
+        monkeypatch.setattr(dist, "all_to_all", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        parts = tdist.shuffle_by_key(d(kr), cols, owners=plan, ts=cols[0], halo=True)
+        torch.cuda.synchronize()
+        assert len(calls) >= 25 + 13 + 4 + 13           # rounds of the 8-, 8-, 1- and 4-byte columns (+ key)
+        assert parts[2] == whole[2] == [n] and parts[3] == whole[3] == [n]
+        assert torch.equal(parts[0], whole[0]) and np.array_equal(parts[0].cpu().numpy(), kr)
+        for a, b, src in zip(parts[1], whole[1], [tr, x, flag, small]):
+            assert torch.equal(a, b) and np.array_equal(a.cpu().numpy(), src)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("n,world", [(400_000, 8), (70_001, 3), (50, 2), (1_300_000, 64), (0, 4)])
 def test_partition_move_equals_partition_plus_gather(n, world):
     """The fused route-and-move call delivers what tmp_hash_partition + one gather per column
