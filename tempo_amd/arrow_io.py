@@ -32,29 +32,36 @@ def encode_keys(tables, cols):
     if not cols:
         return [None for _ in tables], 1, (lambda codes: [])
     lens = [t.num_rows for t in tables]
-    combined, dicts = None, []
+    dense, dicts, col_codes = None, [], []
     for c in cols:
         whole = pa.concat_arrays([_combined(t[c]) for t in tables])
         enc = pc.dictionary_encode(whole, null_encoding="encode")
         codes = enc.indices.to_numpy(zero_copy_only=False).astype(np.int64)
         dicts.append(enc.dictionary)
-        combined = codes if combined is None else combined * max(len(enc.dictionary), 1) + codes
-    radix = [max(len(d), 1) for d in dicts]
+        col_codes.append(codes)
+        if dense is None:
+            dense = codes
+        else:
+            # re-densified after every column: the running code stays below the row count, so
+            # (rows x cardinality) cannot wrap int64 however many columns there are
+            _, dense = np.unique(dense * max(len(enc.dictionary), 1) + codes, return_inverse=True)
+            dense = dense.astype(np.int64)
     if len(cols) > 1:
-        uniq, dense = np.unique(combined, return_inverse=True)
+        n_keys = int(dense.max()) + 1 if len(dense) else 1
+        # one row per key id, to read the key's per-column dictionary codes back from
+        _, first_row = np.unique(dense, return_index=True)
     else:
-        uniq, dense = np.arange(radix[0], dtype=np.int64), combined
-    n_keys = int(len(uniq)) if len(uniq) else 1
+        n_keys = max(len(dicts[0]), 1)
+        first_row = None
     if n_keys >= 2 ** 31:
         raise NotImplementedError("more than 2^31 distinct partition keys")
 
     def decode(codes):
-        flat = uniq[np.asarray(codes, dtype=np.int64)]
-        out = []
-        for j in reversed(range(len(cols))):
-            out.append(dicts[j].take(pa.array(flat % radix[j], type=pa.int64())))
-            flat = flat // radix[j]
-        return out[::-1]
+        codes = np.asarray(codes, dtype=np.int64)
+        if first_row is None:
+            return [dicts[0].take(pa.array(codes, type=pa.int64()))]
+        rows = first_row[codes]
+        return [dicts[j].take(pa.array(col_codes[j][rows], type=pa.int64())) for j in range(len(cols))]
 
     parts, at = [], 0
     for n in lens:

@@ -70,9 +70,13 @@ def encode_keys(frames, cols):
         vals = pd.concat([f[c] for f in frames], ignore_index=True)
         codes, uniq = pd.factorize(vals, use_na_sentinel=False)
         codes = codes.astype(np.int64)
-        combined = codes if combined is None else combined * max(len(uniq), 1) + codes
-    if len(cols) > 1:
-        combined, uniq = pd.factorize(combined)
+        if combined is None:
+            combined = codes
+        else:
+            # the running code is re-factorized after every column, so it stays below the row
+            # count and (rows x cardinality) cannot wrap int64 however many columns there are
+            combined, _ = pd.factorize(combined * max(len(uniq), 1) + codes)
+            combined = combined.astype(np.int64)
     n_keys = int(combined.max()) + 1 if len(combined) else 1
     if n_keys >= 2 ** 31:
         raise NotImplementedError("more than 2^31 distinct partition keys")

@@ -17,7 +17,12 @@ from . import ops
 
 # Largest single message handed to the collective, in bytes.  Columns of 10^9 rows are several
 # GB per peer; they go out as a sequence of all-to-alls over row ranges of at most this size.
-MAX_MESSAGE_BYTES = 1 << 30
+# Why: on this RCCL build a rank's send to itself delivers a message of 1 GiB intact but only
+# the first half of one between 2 GiB and 8 GB (the tail of the receive buffer is left untouched;
+# every entry point -- all_to_all_single with or without split sizes and the grouped send/recv
+# form -- behaves the same, so the loss is below torch; tools/a2a_probe.py reproduces it).
+# Half a GiB keeps every message a factor of two clear of the largest size seen to work.
+MAX_MESSAGE_BYTES = 1 << 29
 
 
 def _hip_partition(key, n_parts, table=None, slices=None, ts=None, halo=False):
@@ -214,7 +219,8 @@ def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
     tensors are staged through host memory first."""
     if _host_staged(group, staged):
         h_got = torch.empty(got.shape, dtype=got.dtype)
-        _exchange(staged.cpu(), h_got, send_l, recv_l, rounds, rows_per_round, group)
+        for w in _exchange(staged.cpu(), h_got, send_l, recv_l, rounds, rows_per_round, group):
+            w.wait()
         got.copy_(h_got)
         return []
     if rounds == 1:

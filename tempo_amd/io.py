@@ -46,7 +46,15 @@ def warehouse_dir(spark):
 
 
 def table_path(spark, tabName):
-    return os.path.join(warehouse_dir(spark), tabName)
+    """Directory of table `tabName` inside the warehouse.  The name must stay inside it: empty
+    names, absolute paths and names that climb out through '..' are rejected."""
+    if not isinstance(tabName, str) or not tabName.strip():
+        raise ValueError("tabName must be a non-empty table name")
+    root = os.path.realpath(warehouse_dir(spark))
+    path = os.path.realpath(os.path.join(root, tabName))
+    if os.path.isabs(tabName) or path == root or os.path.commonpath([root, path]) != root:
+        raise ValueError(f"tabName {tabName!r} does not name a table inside the warehouse {root!r}")
+    return path
 
 
 def _schema_string(df, partition_col):
@@ -93,10 +101,35 @@ def write(tsdf, spark, tabName, optimizationCols=None):
     view_cols.rotate(1)  # io.py:31-33: event_time moves to the front
     view_df = view_df[list(view_cols)]
 
-    path = table_path(spark, tabName)
-    if os.path.isdir(path):  # mode("overwrite")
-        shutil.rmtree(path)
+    final_path = table_path(spark, tabName)
+    if os.path.exists(final_path) and not os.path.isdir(os.path.join(final_path, "_delta_log")):
+        # mode("overwrite") replaces a Delta table, never an arbitrary directory or file
+        raise ValueError(f"{final_path!r} exists and is not a Delta table (no _delta_log); not overwriting it")
+    # the new table is built in a sibling directory and swapped in after its commit file is
+    # written, so a failure on the way leaves the previous table as it was
+    os.makedirs(os.path.dirname(final_path), exist_ok=True)
+    path = f"{final_path}.__writing-{uuid.uuid4().hex}"
     os.makedirs(os.path.join(path, "_delta_log"))
+    try:
+        _write_files(path, view_df, days, partitionCols, optimizationCols)
+    except BaseException:
+        shutil.rmtree(path, ignore_errors=True)
+        raise
+    old = None
+    if os.path.isdir(final_path):
+        old = f"{final_path}.__old-{uuid.uuid4().hex}"
+        os.replace(final_path, old)
+    os.replace(path, final_path)
+    if old:
+        shutil.rmtree(old, ignore_errors=True)
+    logger.info("wrote %d rows to %s, clustered by %s", len(view_df), final_path, partitionCols + [ts_col])
+
+
+def _write_files(path, view_df, days, partitionCols, optimizationCols):
+    """Parquet files under event_dt=.../ and the single commit of _delta_log, into `path`."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
     now_ms = int(time.time() * 1000)
     actions = [
         {"commitInfo": {"timestamp": now_ms, "operation": "CREATE OR REPLACE TABLE AS SELECT",
@@ -126,8 +159,6 @@ def write(tsdf, spark, tabName, optimizationCols=None):
     with open(os.path.join(path, "_delta_log", "%020d.json" % 0), "w") as f:
         for a in actions:
             f.write(json.dumps(a, separators=(",", ":")) + "\n")
-    logger.info("wrote %d rows in %d date partitions to %s, clustered by %s", len(view_df), len(starts),
-                path, partitionCols + [ts_col])
 
 
 def read_table(spark, tabName):

@@ -34,3 +34,27 @@ def test_timestamps_to_microseconds(unit, scale):
         arrow_io.timestamps_us(pa.array([None, 1], type=pa.timestamp("us")))
     with pytest.raises(TypeError):
         arrow_io.timestamps_us(pa.array([1, 2]))
+
+
+def test_many_wide_key_columns_do_not_collide():
+    """Five partition columns of ~7000 distinct values each: the product of the cardinalities
+    (1.7e19) exceeds int64, the combined key must still be collision free."""
+    import pandas as pd
+
+    from tempo_amd import columns
+    rng = np.random.default_rng(0)
+    n, ncol, card = 30_000, 5, 7000
+    vals = rng.integers(0, card, (n, ncol))
+    vals[n // 2:] = vals[: n - n // 2]                # every combination occurs twice
+    names = [f"k{j}" for j in range(ncol)]
+    df = pd.DataFrame({nm: vals[:, j] for j, nm in enumerate(names)})
+    want = len(set(map(tuple, vals.tolist())))
+    (codes,), n_keys = columns.encode_keys([df], names)
+    assert n_keys == want and len(np.unique(codes)) == want
+    assert np.array_equal(codes[: n - n // 2], codes[n // 2:])
+    tbl = pa.table({nm: vals[:, j] for j, nm in enumerate(names)})
+    (acodes,), an, decode = arrow_io.encode_keys([tbl], names)
+    assert an == want and np.array_equal(acodes[: n - n // 2], acodes[n // 2:])
+    back = decode(acodes)
+    for j in range(ncol):
+        assert back[j].to_pylist() == vals[:, j].tolist()

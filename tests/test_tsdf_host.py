@@ -69,3 +69,21 @@ def test_key_encoding_is_shared_across_frames():
     assert ca[1] == cb[0] and n == 4
     (ca, cb), n = columns.encode_keys([a, b], [])
     assert ca is None and cb is None and n == 1
+
+
+def test_table_path_stays_inside_the_warehouse(tmp_path):
+    """io.write replaces a directory: the table name may not be empty, absolute or climb out of
+    the warehouse, and the path it resolves to lies strictly below the warehouse root."""
+    import os
+
+    import pytest
+
+    from tempo_amd import io as tio
+    root = str(tmp_path / "wh")
+    assert tio.table_path(root, "my_table") == os.path.join(os.path.realpath(root), "my_table")
+    assert tio.table_path(root, "db/tab") == os.path.join(os.path.realpath(root), "db", "tab")
+    for bad in ("", "  ", ".", "..", "../x", "a/../..", "/etc", str(tmp_path), "a/../../wh2"):
+        with pytest.raises(ValueError):
+            tio.table_path(root, bad)
+    with pytest.raises(ValueError):
+        tio.table_path(root, None)

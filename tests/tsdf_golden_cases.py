@@ -312,6 +312,16 @@ def case_write_to_delta(TSDF):
         assert len(tio.read_table(root, "my_table")) == 3
         with pytest.raises(ValueError):
             TSDF(df, partition_cols=["symbol"]).write(root, "my_table", optimizationCols=["nope"])
+        # only a Delta table is ever replaced, and only inside the warehouse
+        os.makedirs(os.path.join(root, "plain_dir"))
+        with open(os.path.join(root, "plain_dir", "keep.txt"), "w") as f:
+            f.write("x")
+        with pytest.raises(ValueError, match="not a Delta table"):
+            TSDF(df, partition_cols=["symbol"]).write(root, "plain_dir")
+        assert os.path.exists(os.path.join(root, "plain_dir", "keep.txt"))
+        with pytest.raises(ValueError):
+            TSDF(df, partition_cols=["symbol"]).write(root, "../escaped")
+        assert sorted(os.listdir(root)) == ["my_table", "plain_dir"]     # no staging directory left behind
 
 
 ALL_CASES = [case_asof_basic, case_asof_skip_nulls, case_asof_sequence, case_asof_skew, case_range_stats,
