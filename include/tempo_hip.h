@@ -208,6 +208,9 @@ int tmp_range_stats(const tmp_range_stats_args *a, void *workspace, size_t works
  * out[p] = 0 + w[0]*x[p] + w[1]*x[p-1] + ... (left-to-right adds, NULL or missing taps add
  * nothing), rows ordered as tsdf.py:563-572.  weights: HOST array of n_taps doubles computed
  * by the caller as exp_factor * (1 - exp_factor) ** i (tsdf.py:629).  n_taps <= TMP_MAX_TAPS.
+ * The array has been copied to the device by the time the call returns (the copy is enqueued
+ * ahead of the host read of the key ranges, which waits for the stream): the caller may free
+ * or reuse it right away.
  * Output in sorted order with out_perm as above.
  */
 #define TMP_MAX_TAPS 1024

@@ -176,6 +176,12 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   s.masks[0] = a->x_valid;
   Layout lay;
   OrderResult res;
+  int taps = a->n_taps;  // zero taps: the column stays lit(0)
+  // The tap weights go to the device ahead of the range scan: the host read of the ranges below
+  // waits for the stream, so the caller's (pageable) array has been consumed before this call
+  // returns and may be released right after it.
+  if (taps > 0)
+    TMP_CHECK_HIP(hipMemcpyAsync(p.w, a->weights, sizeof(double) * taps, hipMemcpyHostToDevice, st));
   TMP_TRY(order_scan_ranges(s, p.ob, st));
   RangeInfo r;
   TMP_TRY(order_read_ranges(p.ob, &r, st));
@@ -185,9 +191,6 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   uint64_t *pay_out[1] = {(uint64_t *)p.xs};
   TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
   const double *xs = carried ? p.xs : a->x;
-  int taps = a->n_taps;  // zero taps: the column stays lit(0)
-  if (taps > 0)
-    TMP_CHECK_HIP(hipMemcpyAsync(p.w, a->weights, sizeof(double) * taps, hipMemcpyHostToDevice, st));
   size_t shm = (size_t)((taps > 0 ? taps - 1 : 0) + EM_ROWS) * 12 + (size_t)(taps > 0 ? taps : 1) * 8;
   int grid = (int)((a->n + EM_ROWS - 1) / EM_ROWS);
   {
