@@ -468,6 +468,20 @@ size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a);
 int tmp_hash_partition(const tmp_partition_args *a, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* tmp_hash_partition for callers that cannot allocate device memory and therefore have no
+ * workspace to pass: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  (No counterpart in the reference: Spark allocates its shuffle buffers itself.)
+ * Same arguments, outputs and errors as tmp_hash_partition; the scratch (radix ping-pong buffers,
+ * digit counters) is a fixed array inside the library's device code, TMP_STATIC_PARTITION_MAX_ROWS
+ * * 24 bytes + 4 MiB, held once per GPU the library is used on until the process ends.  Calls
+ * with more rows return TMP_ECAPACITY and write nothing.  The call allocates and frees nothing
+ * (the first call on a device looks the array's address up, once).  All calls on one GPU share
+ * the array: two calls that overlap on the same GPU (different streams or threads) race; calls on
+ * one stream, or on different GPUs, do not.
+ */
+#define TMP_STATIC_PARTITION_MAX_ROWS 1048576
+int tmp_hash_partition_static(const tmp_partition_args *a, void *stream);
+
 /* Route and move in one call: what tmp_hash_partition + one tmp_gather per column deliver, without
  * row ids or sort passes, for up to 64 parts.  `route` is read like tmp_hash_partition's
  * argument (out_perm is not used); afterwards out_cols[c][first(r) + j] = cols[c][i_j], i_j the

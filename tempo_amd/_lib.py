@@ -16,6 +16,7 @@ TMP_MAX_FEATURES = 64
 TMP_MAX_COLS = 64
 TMP_ECAPACITY = -5
 TMP_EWIDE = -6
+TMP_STATIC_PARTITION_MAX_ROWS = 1048576
 FUNC_CODES = {"floor": 0, "min": 1, "max": 2, "mean": 3, "ceil": 4}
 
 _vp = C.c_void_p
@@ -141,6 +142,7 @@ SYMBOLS = {
     "tmp_interpolate": _OP(InterpolateArgs),
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
+    "tmp_hash_partition_static": (C.c_int, [C.POINTER(PartitionArgs), _vp]),
     "tmp_partition_move_workspace_bytes": _WS(PartitionMoveArgs),
     "tmp_partition_move": _OP(PartitionMoveArgs),
     "tmp_key_counts_workspace_bytes": _WS(KeyCountsArgs),

@@ -4,6 +4,8 @@
 // The bucketing is one stable radix pass of the ordering step with the owner as the digit.
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "skew.h"
 
@@ -328,24 +330,22 @@ extern "C" size_t tmp_hash_partition_workspace_bytes(const tmp_partition_args *a
   return ws.off;
 }
 
-extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
-                                  size_t workspace_bytes, void *stream) {
+static int hash_partition_run(const tmp_partition_args *a, void *workspace, size_t workspace_bytes,
+                              void *stream, const char *who) {
   clear_error();
-  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_hash_partition: null args");
-  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31), TMP_EINVAL, "tmp_hash_partition: bad row count");
-  TMP_REQUIRE(a->n_parts >= 1 && a->n_parts <= 256, TMP_EINVAL,
-              "tmp_hash_partition: n_parts must be in [1, 256]");
-  TMP_REQUIRE(a->out_counts, TMP_EINVAL, "tmp_hash_partition: out_counts is null");
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "%s: null args", who);
+  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31), TMP_EINVAL, "%s: bad row count", who);
+  TMP_REQUIRE(a->n_parts >= 1 && a->n_parts <= 256, TMP_EINVAL, "%s: n_parts must be in [1, 256]", who);
+  TMP_REQUIRE(a->out_counts, TMP_EINVAL, "%s: out_counts is null", who);
   hipStream_t st = (hipStream_t)stream;
   TMP_CHECK_HIP(hipMemsetAsync(a->out_counts, 0, sizeof(int64_t) * a->n_parts, st));
   if (a->n == 0) return TMP_OK;
-  TMP_REQUIRE(a->key && a->out_perm, TMP_EINVAL, "tmp_hash_partition: null pointer");
+  TMP_REQUIRE(a->key && a->out_perm, TMP_EINVAL, "%s: null pointer", who);
   Workspace ws(workspace, workspace_bytes);
   OrderBuffers b;
   order_plan(a->n, ws, &b);
-  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_hash_partition: workspace too small");
-  TMP_REQUIRE(!a->owner_table || a->n_keys >= 1, TMP_EINVAL,
-              "tmp_hash_partition: owner_table needs n_keys >= 1");
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "%s: workspace too small", who);
+  TMP_REQUIRE(!a->owner_table || a->n_keys >= 1, TMP_EINVAL, "%s: owner_table needs n_keys >= 1", who);
   SliceArgs sl;
   TMP_TRY(slice_args(a, &sl));
   TMP_LAUNCH(owner_kernel, dim3(grid_for(a->n, kBlock * 8, 2048)), dim3(kBlock), st, a->key, a->n,
@@ -358,6 +358,54 @@ extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
              a->out_perm, a->n);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
+}
+
+extern "C" int tmp_hash_partition(const tmp_partition_args *a, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+  return hash_partition_run(a, workspace, workspace_bytes, stream, "tmp_hash_partition");
+}
+
+// ---- tmp_hash_partition without a workspace argument: the radix ping-pong buffers and digit
+// counters live in a device array of this code object.  Every GPU the library runs on holds its
+// own copy of the array at its own address (until the process ends); host code only ever uses
+// the per-device address hipGetSymbolAddress returns, never the array's name.
+constexpr int64_t kStaticMaxRows = TMP_STATIC_PARTITION_MAX_ROWS;
+// what the ordering step takes for kStaticMaxRows rows (two 8-byte and two 4-byte arrays per
+// row) plus 4 MiB for its digit counters and small records; the entry point checks the exact
+// need of every call against this
+constexpr size_t kStaticScratchBytes = (size_t)kStaticMaxRows * 24 + ((size_t)4 << 20);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[kMaxDevices];  // [device ordinal], filled on the first call per device
+
+extern "C" int tmp_hash_partition_static(const tmp_partition_args *a, void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_hash_partition_static: null args");
+  TMP_REQUIRE(a->n <= kStaticMaxRows, TMP_ECAPACITY,
+              "tmp_hash_partition_static: %lld rows exceed the built-in scratch (at most %lld rows); "
+              "use tmp_hash_partition with a workspace", (long long)a->n, (long long)kStaticMaxRows);
+  const size_t need = tmp_hash_partition_workspace_bytes(a);
+  TMP_REQUIRE(need <= kStaticScratchBytes, TMP_ECAPACITY,
+              "tmp_hash_partition_static: needs %zu bytes of scratch, %zu are built in", need, kStaticScratchBytes);
+  int dev = -1;
+  TMP_CHECK_HIP(hipGetDevice(&dev));
+  TMP_REQUIRE(dev >= 0 && dev < kMaxDevices, TMP_EUNSUPPORTED, "tmp_hash_partition_static: device ordinal %d", dev);
+  void *ptr;
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {  // once per device, with that device current
+      void *p = nullptr;
+      TMP_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      TMP_REQUIRE(p != nullptr, TMP_EHIP, "tmp_hash_partition_static: no device address for the scratch array");
+      g_scratch_ptr[dev] = p;
+    }
+    ptr = g_scratch_ptr[dev];
+  }
+  // Nothing in the scratch has to start at zero: the routing kernel writes every word / row id,
+  // each pass's histogram kernel writes every counter before the scan reads it.
+  return hash_partition_run(a, ptr, kStaticScratchBytes, stream, "tmp_hash_partition_static");
 }
 
 extern "C" size_t tmp_key_counts_workspace_bytes(const tmp_key_counts_args *) { return 0; }

@@ -459,7 +459,7 @@ def _route_args(a, key, n_parts, owner_table, slices, ts, halo):
         raise ValueError("halo routing needs sliced keys")
 
 
-def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=False):
+def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=False, static_scratch=False):
     """Bucket rows by owner: owner_table[key] when a table (int32[n_keys], device) is given, else
     hash(key) % n_parts.  Returns (perm int32[n], counts int64[n_parts]).
 
@@ -467,12 +467,19 @@ def hash_partition(key, n_parts, owner_table=None, slices=None, ts=None, halo=Fa
     ts_partition_val, v_is_int, one_minus_fraction, ts_is_seconds, bracket_min, bracket_count and
     the device int32 tensors split_slices, split_first, slice_owner (include/tempo_hip.h,
     tmp_partition_args).  halo=True routes the copies of carried-over rows instead of the rows;
-    only the first counts.sum() entries of perm are meaningful then."""
+    only the first counts.sum() entries of perm are meaningful then.
+
+    static_scratch=True goes through tmp_hash_partition_static: no workspace is allocated, the
+    library's built-in device array serves instead (at most _lib.TMP_STATIC_PARTITION_MAX_ROWS
+    rows; more raise)."""
     perm = torch.empty(key.numel(), dtype=torch.int32, device=key.device)
     counts = torch.zeros(n_parts, dtype=torch.int64, device=key.device)
     a = PartitionArgs()
     _route_args(a, key, n_parts, owner_table, slices, ts, halo)
     a.out_perm, a.out_counts = _p(perm), _p(counts)
+    if static_scratch:
+        check(lib().tmp_hash_partition_static(C.byref(a), _stream()), "tmp_hash_partition_static")
+        return perm, counts
     ws = _workspace(lib().tmp_hash_partition_workspace_bytes(C.byref(a)), key.device)
     check(lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), _stream()),
           "tmp_hash_partition")
