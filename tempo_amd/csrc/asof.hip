@@ -408,8 +408,8 @@ __global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
 }
 
 static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
-  order_plan(a->n_left, ws, &p->lb);
-  order_plan(a->n_right, ws, &p->rb);
+  order_plan(a->n_left, ws, &p->lb, plan_keys(a->key_left, a->n_keys));
+  order_plan(a->n_right, ws, &p->rb, plan_keys(a->key_right, a->n_keys));
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());

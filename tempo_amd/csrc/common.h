@@ -75,6 +75,7 @@ struct Layout {
   int prim_bits;
   int key_bits;
   int64_t prim_min;
+  int64_t prim_max;
   int64_t seq_min;
   int64_t prim_div;
   int64_t prim_gran;
@@ -123,6 +124,14 @@ struct OrderBuffers {
   uint32_t *idx[2];
   uint32_t *counts;
   RangeInfo *range;  // device
+  // bucketed ordering (see order.hip); all null when the table is too small for it
+  unsigned long long *key_rows;  // [n_keys] sampled rows per key
+  uint32_t *key_nb;              // [n_keys] buckets of the key
+  uint32_t *key_base;            // [n_keys] first bucket of the key
+  uint32_t *bucket_key;          // [max_buckets] key id of every bucket
+  int32_t *fallback;             // device flag: some tile did not fit, the plain passes redo the job
+  int64_t max_buckets;
+  const int32_t *run_if;         // host-side switch: non-null while the stand-by passes are enqueued
 };
 
 struct OrderResult {
@@ -130,7 +139,10 @@ struct OrderResult {
   const uint32_t *perm;  // perm[p] = input row at sorted position p
 };
 
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b);
+// n_keys > 0 also reserves what the bucketed ordering of a large table needs.
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys = 0);
+// Size of the key dictionary as the ordering step sees it (a table without keys is one series).
+inline int64_t plan_keys(const void *key, int64_t n_keys) { return key ? (n_keys > 0 ? n_keys : 1) : 1; }
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st);
 int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st);
 int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layout *out);

@@ -260,7 +260,7 @@ struct LbPlan {
 };
 
 static void lb_plan(const tmp_lookback_args *a, Workspace &ws, LbPlan *p) {
-  order_plan(a->n, ws, &p->ob);
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys));
   size_t cnt = (size_t)(a->n > 0 ? a->n : 1);
   p->nblocks = (int)((cnt + LB_ROWS - 1) / LB_ROWS);
   p->full = ws.take<uint8_t>(cnt);

@@ -200,6 +200,12 @@ struct GenArgs {
   int n_masks;
   MaskPtrs masks;
   int id_bits;  // > 0: the radix passes carry the row id in that many bits below the word
+  // bucketed ordering: the top field holds key_base[key] + floor(nb * rel / (rel_max + 1)) -- the
+  // row's bucket -- instead of the key id (rel = the row's time field, inv = ceil(2^64 / (rel_max + 1)))
+  const uint32_t *key_nb;
+  const uint32_t *key_base;
+  uint64_t inv;
+  uint32_t last_key;  // n_keys - 1: key ids beyond the dictionary are read as the last key
 };
 
 __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
@@ -208,7 +214,16 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   uint64_t rel = (uint64_t)(p - lay.prim_min);
   if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
   uint64_t w = rel << lay.prim_shift();
-  if (lay.key_bits) w |= (uint64_t)(uint32_t)g.key[i] << lay.key_shift();
+  if (g.key_nb) {
+    uint32_t k = g.key ? (uint32_t)g.key[i] : 0u;
+    k = k < g.last_key ? k : g.last_key;
+    const uint32_t nb = g.key_nb[k];
+    uint64_t q = __umul64hi(rel * nb, g.inv);
+    if (q >= nb) q = nb - 1;
+    w |= (uint64_t)(g.key_base[k] + (uint32_t)q) << lay.key_shift();
+  } else if (lay.key_bits) {
+    w |= (uint64_t)(uint32_t)g.key[i] << lay.key_shift();
+  }
   if (lay.seq_bits && g.seq) {
     bool sv = !g.seq_valid || g.seq_valid[i];
     if (sv) w |= (uint64_t)(g.seq[i] - lay.seq_min + 1) << lay.seq_shift();
@@ -259,10 +274,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
                                                                 uint32_t *counts, GenArgs gen,
-                                                                uint64_t *words) {
+                                                                uint64_t *words, const int32_t *run_if) {
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   constexpr int RS_RADIX = 1 << RS_BITS;
+  if (run_if && !*run_if) return;  // a pass of the stand-by sort: runs only if the bucketed one gave up
   __shared__ uint32_t hist[RS_WAVES][RS_RADIX];
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&hist[0][0])[i] = 0;
   __syncthreads();
@@ -292,8 +308,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
 
 // Exclusive scan of `total` uint32 counters in place, one block, 16 counters per thread and
 // round (four 16-byte loads; `counts` comes from the 256-byte aligned workspace).
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int total) {
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int total,
+                                                          const int32_t *run_if) {
   constexpr int kPer = 16;
+  if (run_if && !*run_if) return;
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -353,7 +371,7 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, int 
 }
 
 int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
-  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, counts, total);
+  TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, counts, total, (const int32_t *)nullptr);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }
@@ -370,8 +388,9 @@ template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int P
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
-    PayPtrs pp, int id_bits) {
+    PayPtrs pp, int id_bits, const int32_t *run_if) {
   constexpr bool PAY = NPAY > 0;
+  if (run_if && !*run_if) return;
   const uint64_t id_mask = PACK ? ((1ull << id_bits) - 1) : 0ull;
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
@@ -576,10 +595,326 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Bucketed ordering of large tables in random order: two or three partition passes instead of
+// one pass per 8 bits of the sort word.
+//
+// Every row gets a bucket number that is monotone in (key, time): a key owns a run of
+// nb(key) ~ rows(key) / A buckets and a row falls into the one its time selects
+// (key_base + floor(nb * (t - t_min) / (t_max - t_min + 1))).  Where the rows of a key are spread
+// evenly over time a bucket holds about A rows.  The sort word carries the bucket number in its
+// top field in place of the key id; stable LSD passes over that field alone (bucket_bits, 17-18
+// bits for 5x10^8 rows) group the rows by bucket, and a tile kernel then finishes the order
+// inside LDS: a block takes the buckets that start inside its 8192-row stretch (at most 16384
+// rows), restores the key id in the top field (bucket_key), sorts by the bits in which the
+// tile's words actually differ and writes the words and row ids out in one contiguous run.
+//
+// A bucket that turns out longer than a tile can absorb (rows bunched in time, massive
+// duplicates) raises a device flag; the plain LSD passes are always enqueued behind the tile
+// kernel, every one of their kernels returning at once unless that flag is set, so the result
+// is the same either way and the host never waits.
+// ------------------------------------------------------------------------------------------
+constexpr int TS_THREADS = 1024;
+constexpr int TS_ITEMS = 16;
+constexpr int TS_CAP = TS_THREADS * TS_ITEMS;  // most rows one tile can hold
+constexpr int TS_TILE = TS_CAP / 2;            // stretch of rows whose bucket starts a block owns
+constexpr int TS_IDX_BITS = 14;                // bits_for(TS_CAP - 1)
+// Tables below this many rows take the plain passes (TEMPO_BUCKET_MIN_ROWS overrides: tests).
+static int64_t bucket_min_rows() {
+  const char *e = getenv("TEMPO_BUCKET_MIN_ROWS");
+  return e ? (int64_t)atoll(e) : (int64_t)(1 << 22);
+}
+constexpr int kCountStride = 16;               // every 16th row is counted per key
+constexpr int kCountLdsKeys = 12288;
+
+struct BucketGeom {
+  bool ok;
+  int bits;         // width of the bucket field
+  int64_t avg;      // rows per bucket the map aims at
+  int64_t max_buckets;
+};
+
+static BucketGeom bucket_geometry(int64_t n, int64_t n_keys) {
+  BucketGeom g;
+  g.ok = false; g.bits = 0; g.avg = 0; g.max_buckets = 0;
+  if (n < bucket_min_rows() || n_keys < 1) return g;
+  for (int b = 10; b <= 26; ++b) {
+    // every key owns at least one bucket; the counts are estimates from every 16th row
+    const int64_t room = (1ll << b) - n_keys - 2;
+    if (room <= 0) continue;
+    const int64_t a = (n + kCountStride + room - 1) / room;
+    if (a <= TS_TILE * 55 / 100) {
+      g.ok = a >= 64;  // more keys than buckets worth having: the plain passes do as well
+      g.bits = b;
+      g.avg = a;
+      g.max_buckets = 1ll << b;
+      return g;
+    }
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(kBlock) void key_sample_kernel(const int32_t *__restrict__ key, int64_t n_samples,
+                                                              uint32_t n_keys, unsigned long long *rows) {
+  __shared__ unsigned int hist[kCountLdsKeys];
+  const bool local = n_keys <= (uint32_t)kCountLdsKeys;
+  if (local) {
+    for (uint32_t i = threadIdx.x; i < n_keys; i += kBlock) hist[i] = 0;
+    __syncthreads();
+  }
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_samples; s += step) {
+    const uint32_t k = key ? (uint32_t)key[s * kCountStride] : 0u;
+    if (k >= n_keys) continue;
+    if (local) atomicAdd(&hist[k], 1u);
+    else atomicAdd(&rows[k], 1ull);
+  }
+  if (local) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_keys; i += kBlock)
+      if (hist[i]) atomicAdd(&rows[i], (unsigned long long)hist[i]);
+  }
+}
+
+// nb(key) = max(1, ceil(estimated rows / avg)), into both arrays (key_base is scanned afterwards)
+__global__ void bucket_nb_kernel(const unsigned long long *rows, uint32_t n_keys, uint64_t avg, uint32_t *key_nb,
+                                 uint32_t *key_base) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_keys) return;
+  uint64_t est = rows[k] * (uint64_t)kCountStride;
+  uint64_t nb = (est + avg - 1) / avg;
+  if (nb < 1) nb = 1;
+  key_nb[k] = (uint32_t)nb;
+  key_base[k] = (uint32_t)nb;
+}
+
+// bucket_key[b] = the key whose run of buckets holds b (largest k with key_base[k] <= b)
+__global__ void bucket_key_kernel(const uint32_t *key_base, const uint32_t *key_nb, uint32_t n_keys,
+                                  uint32_t max_buckets, uint32_t *bucket_key) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= max_buckets) return;
+  const uint32_t total = key_base[n_keys - 1] + key_nb[n_keys - 1];
+  if (b >= total) return;
+  uint32_t lo = 0, hi = n_keys;  // first k with key_base[k] > b
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (key_base[mid] <= b) lo = mid + 1;
+    else hi = mid;
+  }
+  bucket_key[b] = lo - 1;
+}
+
+// First position p in [from, to) at which a bucket starts (p == 0, or the top field differs from
+// the row before); `to` if there is none.  Whole block; red: NT / 64 + 1 slots of LDS.
+template <int NT>
+__device__ __forceinline__ int64_t first_bucket_start(const uint64_t *w, int64_t from, int64_t to, int top_shift,
+                                                      int64_t *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int64_t base = from; base < to; base += NT) {
+    const int64_t p = base + threadIdx.x;
+    bool hit = false;
+    if (p < to) hit = p == 0 || (w[p] >> top_shift) != (w[p - 1] >> top_shift);
+    const uint64_t bal = __ballot(hit);
+    if (lane == 0) red[wave] = bal ? base + wave * 64 + (__ffsll((long long)bal) - 1) : INT64_MAX;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t m = INT64_MAX;
+      for (int i = 0; i < NT / 64; ++i) m = red[i] < m ? red[i] : m;
+      red[NT / 64] = m;
+    }
+    __syncthreads();
+    const int64_t got = red[NT / 64];
+    __syncthreads();
+    if (got != INT64_MAX) return got;
+  }
+  return to;
+}
+
+template <int NT, int NI>
+__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, const uint32_t *idin, uint64_t *wout,
+                                                       uint32_t *idout, int64_t n, int top_shift, int low_bits,
+                                                       const uint32_t *bucket_key, int32_t *fallback, PayPtrs pp, int dbg_max_passes) {
+  constexpr int CAP = NT * NI, TILE = CAP / 2, NW = NT / 64;
+  __shared__ uint64_t sbuf[CAP];
+  __shared__ uint32_t whist[NW][256];
+  __shared__ uint32_t dstart[256];
+  __shared__ uint32_t wtot[4];
+  __shared__ int64_t red[NW + 1];
+  __shared__ uint64_t red_min[NW], red_max[NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t t0 = (int64_t)blockIdx.x * TILE;
+  const int64_t t1 = t0 + TILE < n ? t0 + TILE : n;
+  // the block owns the buckets that start in [t0, t1): rows [s, e)
+  const int64_t s = first_bucket_start<NT>(win, t0, t1, top_shift, red);
+  if (s >= t1) return;  // a bucket that began earlier covers the whole stretch
+  int64_t e = n;
+  if (t1 < n) {
+    const int64_t lim = s + CAP + 1 < n ? s + CAP + 1 : n;
+    e = first_bucket_start<NT>(win, t1, lim, top_shift, red);
+    if (e == lim && lim < n) e = INT64_MAX;  // no bucket starts within reach
+  }
+  if (e == INT64_MAX || e - s > CAP) {
+    if (tid == 0) atomicOr(fallback, 1);
+    return;
+  }
+  const int m = (int)(e - s);
+  // wave w works on slots [w * chunk, (w + 1) * chunk), nit items per lane
+  const int nit = (m + NT - 1) / NT;
+  const int chunk = nit * 64;
+  const uint64_t field_mask = (top_shift >= 64) ? ~0ull : ((1ull << top_shift) - 1);
+  uint64_t wv[NI];
+  uint64_t mn = ~0ull, mx = 0ull;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    wv[it] = 0;
+    const int j = wave * chunk + it * 64 + lane;
+    if (it < nit && j < m) {
+      const uint64_t w = win[s + j];
+      const uint64_t top = bucket_key ? (uint64_t)bucket_key[w >> top_shift] : (w >> top_shift);
+      const uint64_t v = top_shift >= 64 ? w : ((top << top_shift) | (w & field_mask));
+      wv[it] = v;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (lane == 0) { red_min[wave] = mn; red_max[wave] = mx; }
+  __syncthreads();
+  mn = red_min[0]; mx = red_max[0];
+  for (int i = 1; i < NW; ++i) {
+    mn = red_min[i] < mn ? red_min[i] : mn;
+    mx = red_max[i] > mx ? red_max[i] : mx;
+  }
+  const uint64_t low_mask = (1ull << low_bits) - 1;
+  const uint64_t wmin = mn & ~low_mask;
+  // bits in which the tile's words differ, above the low bits that are carried but not compared
+  int span = 0;
+  for (uint64_t d = (mx - wmin) >> low_bits; d; d >>= 1) ++span;
+  if (span + low_bits + TS_IDX_BITS > 64) {  // no room for the slot number next to the word
+    if (tid == 0) atomicOr(fallback, 1);
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int j = wave * chunk + it * 64 + lane;
+    if (it < nit && j < m) sbuf[j] = ((wv[it] - wmin) << TS_IDX_BITS) | (uint64_t)j;
+  }
+  int passes = (span + 7) / 8;
+  if (passes > dbg_max_passes) passes = dbg_max_passes;
+#pragma unroll 1
+  for (int p = 0; p < passes; ++p) {
+    const int shift = TS_IDX_BITS + low_bits + 8 * p;
+    for (int i = tid; i < NW * 256; i += NT) (&whist[0][0])[i] = 0;
+    __syncthreads();  // also orders the previous pass's (or the initial) writes of sbuf before the reads
+    // rank of every slot among the slots of its wave with the same digit; only the digit is read
+    // here, the words stay in LDS until the scatter, so few registers are live while ranking
+    uint32_t rk[NI];  // rank | digit << 16, then the slot's destination
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      rk[it] = 0;
+      if (it < nit) {  // wave-uniform
+        const int j = wave * chunk + it * 64 + lane;
+        const bool valid = j < m;
+        const uint32_t d = valid ? (uint32_t)(sbuf[j] >> shift) & 255u : 0u;
+        const uint64_t vb = __ballot(valid);
+        uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
+          const uint64_t bal = __ballot(mb != 0u);
+          plo &= ~((uint32_t)bal ^ mb);
+          phi &= ~((uint32_t)(bal >> 32) ^ mb);
+        }
+        const uint64_t peers = ((uint64_t)phi << 32) | plo;
+        uint32_t prior = __hip_atomic_load(&whist[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+        const bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
+        if (leader)
+          __hip_atomic_store(&whist[wave][d], prior + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        rk[it] = (prior + (uint32_t)__popcll(peers & lt_mask)) | (d << 16);
+      }
+    }
+    __syncthreads();
+    uint32_t cnt_d = 0, cnt_inc = 0;
+    if (tid < 256) {
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = whist[w][tid];
+        whist[w][tid] = cnt_d;
+        cnt_d += c;
+      }
+      uint32_t inc = cnt_d;
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t tt = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += tt;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      cnt_inc = inc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t wp = 0;
+      for (int w = 0; w < wave; ++w) wp += wtot[w];
+      dstart[tid] = wp + cnt_inc - cnt_d;
+    }
+    __syncthreads();
+    // in place: every slot is taken into registers before any slot is rewritten
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      if (it < nit && j < m) {
+        const uint32_t d = rk[it] >> 16;
+        wv[it] = sbuf[j];
+        rk[it] = dstart[d] + whist[wave][d] + (rk[it] & 0xffffu);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      if (it < nit && j < m) sbuf[rk[it]] = wv[it];
+    }
+    __syncthreads();  // the counters are cleared for the next pass only after every slot has used them
+  }
+  __syncthreads();
+  const uint64_t idx_mask = (1ull << TS_IDX_BITS) - 1;
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int j = tid + it * NT;
+    if (j < m) {
+      const uint64_t pk = sbuf[j];
+      wout[s + j] = (pk >> TS_IDX_BITS) + wmin;
+      const uint32_t id = idin[s + (int64_t)(pk & idx_mask)];
+      idout[s + j] = id;
+#pragma unroll
+      for (int c = 0; c < kMaxPay; ++c)
+        if (c < pp.n) pp.out[c][s + j] = pp.src[c][id];
+    }
+  }
+}
+
+// Copies the stand-by sort's result to where the tile kernel would have left it (only when the
+// two end in different halves of the ping-pong buffers, and only if the stand-by ran).
+__global__ void copy_pairs_if_kernel(const uint64_t *win, const uint32_t *idin, uint64_t *wout, uint32_t *idout,
+                                     int64_t n, const int32_t *run_if) {
+  if (!*run_if) return;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    wout[i] = win[i];
+    idout[i] = idin[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
   size_t cnt = (size_t)(n > 0 ? n : 1);
   b->comp[0] = ws.take<uint64_t>(cnt);
   b->comp[1] = ws.take<uint64_t>(cnt);
@@ -587,6 +922,20 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b) {
   b->idx[1] = ws.take<uint32_t>(cnt);
   b->counts = ws.take<uint32_t>(((size_t)1 << RS_MAX_BITS) * RS_MAX_GRID);
   b->range = ws.take<RangeInfo>(1);
+  b->key_rows = nullptr;
+  b->key_nb = b->key_base = b->bucket_key = nullptr;
+  b->fallback = nullptr;
+  b->max_buckets = 0;
+  b->run_if = nullptr;
+  const BucketGeom g = bucket_geometry(n, n_keys);
+  if (g.ok) {
+    b->key_rows = ws.take<unsigned long long>((size_t)n_keys);
+    b->key_nb = ws.take<uint32_t>((size_t)n_keys);
+    b->key_base = ws.take<uint32_t>((size_t)n_keys);
+    b->bucket_key = ws.take<uint32_t>((size_t)g.max_buckets);
+    b->fallback = ws.take<int32_t>(1);
+    b->max_buckets = g.max_buckets;
+  }
 }
 
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
@@ -611,6 +960,7 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
   l.low_bits = low_bits;
   l.prim_div = s.prim_div;
   l.prim_min = r.prim_min <= r.prim_max ? r.prim_min : 0;
+  l.prim_max = r.prim_min <= r.prim_max ? r.prim_max : 0;
   uint64_t prange = r.prim_min <= r.prim_max ? (uint64_t)r.prim_max - (uint64_t)r.prim_min : 0;
   l.prim_gran = 1;
   if (s.coarse_ok) l.prim_gran = !r.not_millions ? 1000000 : (!r.not_thousands ? 1000 : 1);
@@ -646,11 +996,11 @@ static void radix_scatter_launch(OrderBuffers &b, int64_t n, int cur, int shift,
   if (first)
     hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, PACK>), dim3(g.grid), dim3(THREADS),
                        0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
-                       g.tiles_per_block, b.counts, pp, id_bits);
+                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if);
   else
     hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, false, PACK>), dim3(g.grid), dim3(THREADS),
                        0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
-                       g.tiles_per_block, b.counts, pp, id_bits);
+                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if);
 }
 
 // One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.  gen != nullptr: the
@@ -669,14 +1019,14 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
     ProfScope ps(gen ? "radix_hist_kernel+words" : "radix_hist_kernel", st);
     if (gen && gen->id_bits)
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 2>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
     else if (gen)
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 1>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur]);
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
     else
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 0>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr);
-    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid);
+                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr, b.run_if);
+    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid, b.run_if);
   }
   {
     ProfScope ps(NPAY == 0 ? (pack ? "radix_scatter_kernel+ids_in_words" : "radix_scatter_kernel")
@@ -762,6 +1112,25 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
   return radix_passes(b, n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr);
 }
 
+static int passes_for(int bits) {
+  int passes = (bits + 7) / 8;
+  if ((bits + RS_MAX_BITS - 1) / RS_MAX_BITS < passes) passes = (bits + RS_MAX_BITS - 1) / RS_MAX_BITS;
+  return passes;
+}
+
+// The bucketed ordering serves a full sort of a large table whose buffers were planned for it,
+// when the bucket field fits the word and the passes saved outweigh the tile kernel.
+static bool bucketed_wanted(const OrderSpec &s, const Layout &lay, int sorted, const OrderBuffers &b, BucketGeom *g) {
+  if (sorted != 0 || !b.key_nb || !b.fallback) return false;
+  if (getenv("TEMPO_PLAIN_SORT")) return false;  // diagnostic switch: always the plain LSD passes
+  const int64_t nk = plan_keys(s.key, s.n_keys);
+  *g = bucket_geometry(s.n, nk);
+  if (!g->ok || g->max_buckets > b.max_buckets) return false;
+  if (lay.low_bits + lay.seq_bits + lay.prim_bits + g->bits > 64) return false;
+  if (lay.prim_bits + g->bits > 63) return false;  // (time field) x (buckets of a key) is formed in 64 bits
+  return passes_for(lay.total_bits() - lay.low_bits) >= passes_for(g->bits) + 2;
+}
+
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st, int n_pay, const uint64_t *const *pay_src,
                 uint64_t *const *pay_out, bool *carried) {
@@ -782,7 +1151,59 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     TMP_CHECK_HIP(hipGetLastError());
     return TMP_OK;
   }
-  return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
+  BucketGeom bg;
+  if (!bucketed_wanted(s, lay, sorted, b, &bg))
+    return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
+
+  // ---- bucket map: sampled rows per key -> buckets per key -> first bucket per key -> key per bucket
+  const uint32_t nk = (uint32_t)plan_keys(s.key, s.n_keys);
+  TMP_CHECK_HIP(hipMemsetAsync(b.key_rows, 0, sizeof(unsigned long long) * nk, st));
+  TMP_CHECK_HIP(hipMemsetAsync(b.fallback, 0, sizeof(int32_t), st));
+  const int64_t n_samples = (s.n + kCountStride - 1) / kCountStride;
+  TMP_LAUNCH(key_sample_kernel, dim3(grid_for(n_samples, kBlock * 16, 1024)), dim3(kBlock), st, s.key, n_samples,
+             nk, b.key_rows);
+  TMP_LAUNCH(bucket_nb_kernel, dim3((nk + kBlock - 1) / kBlock), dim3(kBlock), st, b.key_rows, nk, (uint64_t)bg.avg,
+             b.key_nb, b.key_base);
+  TMP_TRY(scan_u32_inplace(b.key_base, (int)nk, st));
+  TMP_LAUNCH(bucket_key_kernel, dim3((unsigned)((bg.max_buckets + kBlock - 1) / kBlock)), dim3(kBlock), st, b.key_base,
+             b.key_nb, nk, (uint32_t)bg.max_buckets, b.bucket_key);
+  GenArgs bgen = gen;
+  bgen.key_nb = b.key_nb;
+  bgen.key_base = b.key_base;
+  bgen.last_key = nk - 1;
+  const uint64_t rel_count = ((uint64_t)lay.prim_max - (uint64_t)lay.prim_min) / (uint64_t)lay.prim_gran + 1;  // R
+  bgen.inv = rel_count <= 1 ? 0ull : (~0ull / rel_count) + 1;                                                // ceil(2^64 / R)
+  // ---- partition passes over the bucket field, then the tiles
+  OrderResult part;
+  TMP_TRY(radix_passes(b, s.n, lay.key_shift(), lay.key_shift() + bg.bits, &part, st, 0, nullptr, nullptr, nullptr, &bgen));
+  const int at = part.comp == b.comp[0] ? 0 : 1;
+  PayPtrs pp;
+  memset(&pp, 0, sizeof(pp));
+  TMP_REQUIRE(n_pay <= kMaxPay, TMP_EUNSUPPORTED, "ordering: at most %d payload column(s) per call", kMaxPay);
+  pp.n = n_pay;
+  for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
+  {
+    ProfScope ps("tile_sort_kernel", st);
+    hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS>), dim3((unsigned)((s.n + TS_TILE - 1) / TS_TILE)),
+                       dim3(TS_THREADS), 0, st, b.comp[at], b.idx[at], b.comp[at ^ 1], b.idx[at ^ 1], s.n,
+                       lay.key_shift(), lay.low_bits, b.bucket_key, b.fallback, pp, getenv("TEMPO_DBG_PASSES") ? atoi(getenv("TEMPO_DBG_PASSES")) : 64);
+  }
+  TMP_CHECK_HIP(hipGetLastError());
+  // ---- stand-by: the plain passes, every kernel of which returns at once unless a tile gave up
+  b.run_if = b.fallback;
+  OrderResult plain;
+  int rc = radix_passes(b, s.n, lo_bit, hi_bit, &plain, st, n_pay, pay_src, pay_out, nullptr, &gen);
+  if (rc == TMP_OK && plain.comp != b.comp[at ^ 1]) {
+    TMP_LAUNCH(copy_pairs_if_kernel, dim3(grid_for(s.n, kBlock * 4, 8192)), dim3(kBlock), st, plain.comp, plain.perm,
+               b.comp[at ^ 1], b.idx[at ^ 1], s.n, b.run_if);
+  }
+  b.run_if = nullptr;
+  TMP_TRY(rc);
+  TMP_CHECK_HIP(hipGetLastError());
+  res->comp = b.comp[at ^ 1];
+  res->perm = b.idx[at ^ 1];
+  if (carried) *carried = n_pay > 0;
+  return TMP_OK;
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
@@ -847,7 +1268,7 @@ extern "C" size_t tmp_sort_order_workspace_bytes(const tmp_sort_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   OrderBuffers b;
-  order_plan(a->n, ws, &b);
+  order_plan(a->n, ws, &b, plan_keys(a->key, a->n_keys));
   return ws.off;
 }
 
@@ -859,7 +1280,7 @@ extern "C" int tmp_sort_order(const tmp_sort_args *a, void *workspace, size_t wo
   if (a->n == 0) return TMP_OK;
   Workspace ws(workspace, workspace_bytes);
   OrderBuffers b;
-  order_plan(a->n, ws, &b);
+  order_plan(a->n, ws, &b, plan_keys(a->key, a->n_keys));
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_sort_order: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   Layout lay;

@@ -455,7 +455,7 @@ struct RsPlan {
 };
 
 static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p, bool with_wide) {
-  order_plan(a->n, ws, &p->ob);
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys));
   p->xs = ws.take<uint64_t>((size_t)(a->n > 0 ? a->n : 1));
   p->deferred = ws.take<int32_t>(1);
   if (with_wide) rs_wide_plan(a->n, a->x_is_i64 != 0, ws, &p->wide);

@@ -625,8 +625,8 @@ struct RbPlan {
   int nblocks;
 };
 
-static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p) {
-  order_plan(n, ws, &p->ob);
+static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys) {
+  order_plan(n, ws, &p->ob, n_keys);
   size_t cnt = (size_t)(n > 0 ? n : 1);
   p->nblocks = (int)((cnt + RB_ROWS - 1) / RB_ROWS);
   p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
@@ -643,7 +643,7 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
   return ws.off;
 }
 
@@ -669,7 +669,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -722,7 +722,7 @@ extern "C" size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
   return ws.off;
 }
 
@@ -745,7 +745,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
               TMP_EINVAL, "tmp_grouped_stats: column or output arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));

@@ -70,7 +70,7 @@ extern "C" size_t tmp_write_layout_workspace_bytes(const tmp_write_layout_args *
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   OrderBuffers b;
-  order_plan(a->n, ws, &b);
+  order_plan(a->n, ws, &b, plan_keys(a->key, a->n_keys));
   return ws.off;
 }
 
@@ -84,7 +84,7 @@ extern "C" int tmp_write_layout(const tmp_write_layout_args *a, void *workspace,
   TMP_REQUIRE(!a->key || a->n_keys >= 1, TMP_EINVAL, "tmp_write_layout: n_keys must be >= 1");
   Workspace ws(workspace, workspace_bytes);
   OrderBuffers b;
-  order_plan(a->n, ws, &b);
+  order_plan(a->n, ws, &b, plan_keys(a->key, a->n_keys));
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_write_layout: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_for(a->n, kBlock * 4, 8192);

@@ -1,0 +1,102 @@
+"""The bucketed form of the ordering step (partition passes over a bucket number, in-LDS tile
+sort, plain passes as device-side stand-by): its order must be the oracle's stable order
+(python/tempo/tsdf.py:117-121, :563-572) whether the tiles absorb every bucket or not."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+BASE = 1_596_240_000_000_000
+
+
+def _kernels_of(fn):
+    from tempo_amd import _lib
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    out = fn()
+    torch.cuda.synchronize()
+    names = {}
+    for name, _, ms in _lib.profile_read():
+        names[name] = names.get(name, 0.0) + ms
+    _lib.profile_enable(False)
+    return out, names
+
+
+def _check(orc, key, ts, n_keys, **kw):
+    from tempo_amd import ops
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    perm, names = _kernels_of(lambda: ops.sort_order(d(key), d(ts), n_keys, seq=d(kw.get("seq")),
+                                                      seq_valid=d(kw.get("seq_valid")),
+                                                      floor_seconds=kw.get("floor_seconds", False)))
+    if kw.get("floor_seconds"):   # the oracle's window order: (key, floor(ts / 1e6), seq NULLS FIRST), stable
+        want, _ = orc.window_order(key, ts, seq=kw.get("seq"), seq_valid=kw.get("seq_valid"))
+    else:
+        want = np.lexsort((np.arange(len(ts)), ts, key))
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), np.asarray(want, dtype=np.int64))
+    return names
+
+
+def test_bucketed_uniform_tables_use_the_tile_sort(orc, monkeypatch):
+    monkeypatch.setenv("TEMPO_BUCKET_MIN_ROWS", "3000")
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(0)
+    for n, n_keys in [(300_000, 40), (1_000_003, 1), (200_000, 3000), (90_000, 7)]:
+        w = 1.0 / np.arange(1, n_keys + 1) ** 1.2
+        key = rng.choice(n_keys, n, p=w / w.sum()).astype(np.int32)
+        ts = BASE + rng.integers(0, 86_400_000_000, n)
+        names = _check(orc, key, ts, n_keys)
+        assert "tile_sort_kernel" in names, (n, n_keys, sorted(names))
+
+
+def test_bucketed_bunched_and_duplicated_times_fall_back(orc, monkeypatch):
+    """Buckets assume that a key's rows are spread over its time range; rows bunched into a sliver
+    of it, or sharing one timestamp, overflow a tile -> the stand-by passes must deliver the order."""
+    monkeypatch.setenv("TEMPO_BUCKET_MIN_ROWS", "3000")
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(1)
+    n = 400_000
+    key = rng.integers(0, 5, n).astype(np.int32)
+    # 1: 60 % of the rows inside one second of a day-long range
+    ts = BASE + np.where(rng.random(n) < 0.6, 40_000_000_000 + rng.integers(0, 1_000_000, n),
+                         rng.integers(0, 86_400_000_000, n))
+    _check(orc, key, ts, 5)
+    # 2: one timestamp shared by 100 000 rows of one key (ties keep input order)
+    ts2 = BASE + rng.integers(0, 86_400_000_000, n)
+    ts2[(key == 2) & (rng.random(n) < 0.9)] = BASE + 5_000_000
+    _check(orc, key, ts2, 5)
+    # 3: every row the same (key, ts)
+    _check(orc, np.zeros(n, dtype=np.int32), np.full(n, BASE), 1)
+    # 4: two distinct timestamps only
+    _check(orc, key, BASE + rng.integers(0, 2, n) * 77, 5)
+
+
+def test_bucketed_with_sequence_column_and_seconds_cast(orc, monkeypatch):
+    monkeypatch.setenv("TEMPO_BUCKET_MIN_ROWS", "3000")
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(2)
+    n = 500_000
+    key = rng.integers(0, 30, n).astype(np.int32)
+    ts = BASE + rng.integers(0, 20_000 * 1_000_000, n)
+    seq = rng.integers(0, 1000, n)
+    seq_valid = (rng.random(n) >= 0.2).astype(np.uint8)
+    names = _check(orc, key, ts, 30, seq=seq, seq_valid=seq_valid, floor_seconds=True)
+    assert "tile_sort_kernel" in names
+
+
+def test_bucketed_default_threshold_at_six_million_rows(monkeypatch):
+    """At the library's own size threshold (no override), checked against torch's stable sort."""
+    monkeypatch.delenv("TEMPO_BUCKET_MIN_ROWS", raising=False)
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    from tempo_amd import ops
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    n, n_keys = 6_000_000, 1000
+    key = torch.randint(0, n_keys, (n,), generator=g, device="cuda", dtype=torch.int32)
+    key[: n // 4] = 3                                      # a hot key
+    ts = BASE + torch.randint(0, 86_400_000_000, (n,), generator=g, device="cuda", dtype=torch.int64)
+    perm, names = _kernels_of(lambda: ops.sort_order(key, ts, n_keys))
+    assert "tile_sort_kernel" in names
+    word = (key.to(torch.int64) << 40) | (ts - BASE)
+    want = torch.sort(word, stable=True).indices.to(torch.int32)
+    assert torch.equal(perm, want)
