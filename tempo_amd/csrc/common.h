@@ -130,6 +130,7 @@ struct OrderBuffers {
   uint32_t *key_base;            // [n_keys] first bucket of the key
   uint32_t *bucket_key;          // [max_buckets] key id of every bucket
   int32_t *fallback;             // device flag: some tile did not fit, the plain passes redo the job
+  int64_t *tile_bounds;          // [tiles + 1] first bucket start at or after every tile's first row
   int64_t max_buckets;
   const int32_t *run_if;         // host-side switch: non-null while the stand-by passes are enqueued
 };

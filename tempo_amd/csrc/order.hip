@@ -705,57 +705,74 @@ __global__ void bucket_key_kernel(const uint32_t *key_base, const uint32_t *key_
   bucket_key[b] = lo - 1;
 }
 
-// First position p in [from, to) at which a bucket starts (p == 0, or the top field differs from
-// the row before); `to` if there is none.  Whole block; red: NT / 64 + 1 slots of LDS.
-template <int NT>
-__device__ __forceinline__ int64_t first_bucket_start(const uint64_t *w, int64_t from, int64_t to, int top_shift,
-                                                      int64_t *red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// bounds[g] = first position p >= g * tile at which a bucket starts (p == 0, or the top field
+// differs from the row before), looked for up to g * tile + cap; n when the table ends first,
+// INT64_MAX when no bucket starts within reach.  One wave per entry, g in [0, n_tiles].
+__global__ __launch_bounds__(kBlock) void tile_bounds_kernel(const uint64_t *w, int64_t n, int top_shift, int tile,
+                                                             int cap, int64_t n_tiles, int64_t *bounds) {
+  const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (g > n_tiles) return;
+  const int64_t from = g * tile;
+  int64_t found = INT64_MAX;
+  if (from >= n) {
+    found = n;
+  } else {
+    const int64_t lim = from + cap + 1 < n ? from + cap + 1 : n;
 #pragma unroll 1
-  for (int64_t base = from; base < to; base += NT) {
-    const int64_t p = base + threadIdx.x;
-    bool hit = false;
-    if (p < to) hit = p == 0 || (w[p] >> top_shift) != (w[p - 1] >> top_shift);
-    const uint64_t bal = __ballot(hit);
-    if (lane == 0) red[wave] = bal ? base + wave * 64 + (__ffsll((long long)bal) - 1) : INT64_MAX;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int64_t m = INT64_MAX;
-      for (int i = 0; i < NT / 64; ++i) m = red[i] < m ? red[i] : m;
-      red[NT / 64] = m;
+    for (int64_t base = from; base < lim; base += 256) {
+      const int64_t p0 = base + lane * 4;
+      int hit = 4;  // first of this lane's four positions that starts a bucket
+      if (p0 < lim) {
+        uint64_t prev = p0 > 0 ? w[p0 - 1] >> top_shift : ~0ull;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (p0 + r < lim) {
+            const uint64_t cur = w[p0 + r] >> top_shift;
+            if (hit == 4 && (p0 + r == 0 || cur != prev)) hit = r;
+            prev = cur;
+          }
+        }
+      }
+      const uint64_t bal = __ballot(hit < 4);
+      if (bal) {
+        const int first = __ffsll((long long)bal) - 1;
+        found = base + first * 4 + __shfl(hit, first, 64);
+        break;
+      }
     }
-    __syncthreads();
-    const int64_t got = red[NT / 64];
-    __syncthreads();
-    if (got != INT64_MAX) return got;
+    if (found == INT64_MAX && lim == n) found = n;
   }
-  return to;
+  if (lane == 0) bounds[g] = found;
 }
+
+// TS_BINS bins for the interpolation placement of a tile, two 16-bit counters per LDS word.
+constexpr int TS_BINS = TS_CAP / 2;
+constexpr int TS_DENSE = 64;  // a bin with more slots than this sends its tile to the radix passes
 
 template <int NT, int NI>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, const uint32_t *idin, uint64_t *wout,
                                                        uint32_t *idout, int64_t n, int top_shift, int low_bits,
-                                                       const uint32_t *bucket_key, int32_t *fallback, PayPtrs pp, int dbg_max_passes) {
+                                                       const uint32_t *bucket_key, const int64_t *bounds,
+                                                       int32_t *fallback, PayPtrs pp, int force_radix) {
   constexpr int CAP = NT * NI, TILE = CAP / 2, NW = NT / 64;
+  static_assert(NW * 256 * 4 == TS_BINS * 2 && CAP == TS_CAP, "aux serves both the radix counters and the bins");
   __shared__ uint64_t sbuf[CAP];
-  __shared__ uint32_t whist[NW][256];
+  __shared__ uint32_t aux[NW * 256];  // radix passes: [wave][digit] counters; placement: packed bins
   __shared__ uint32_t dstart[256];
-  __shared__ uint32_t wtot[4];
-  __shared__ int64_t red[NW + 1];
+  __shared__ uint32_t wtot[NW];
   __shared__ uint64_t red_min[NW], red_max[NW];
+  __shared__ int dense_s;
+  uint32_t(*whist)[256] = reinterpret_cast<uint32_t(*)[256]>(aux);
+  uint32_t *sbuf32 = reinterpret_cast<uint32_t *>(sbuf);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int64_t t0 = (int64_t)blockIdx.x * TILE;
   const int64_t t1 = t0 + TILE < n ? t0 + TILE : n;
   // the block owns the buckets that start in [t0, t1): rows [s, e)
-  const int64_t s = first_bucket_start<NT>(win, t0, t1, top_shift, red);
+  const int64_t s = bounds[blockIdx.x];
   if (s >= t1) return;  // a bucket that began earlier covers the whole stretch
-  int64_t e = n;
-  if (t1 < n) {
-    const int64_t lim = s + CAP + 1 < n ? s + CAP + 1 : n;
-    e = first_bucket_start<NT>(win, t1, lim, top_shift, red);
-    if (e == lim && lim < n) e = INT64_MAX;  // no bucket starts within reach
-  }
+  const int64_t e = bounds[blockIdx.x + 1];
   if (e == INT64_MAX || e - s > CAP) {
     if (tid == 0) atomicOr(fallback, 1);
     return;
@@ -766,13 +783,17 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
   const int chunk = nit * 64;
   const uint64_t field_mask = (top_shift >= 64) ? ~0ull : ((1ull << top_shift) - 1);
   uint64_t wv[NI];
+  uint32_t idv[NI];
   uint64_t mn = ~0ull, mx = 0ull;
+  if (tid == 0) dense_s = force_radix;
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     wv[it] = 0;
+    idv[it] = 0;
     const int j = wave * chunk + it * 64 + lane;
     if (it < nit && j < m) {
       const uint64_t w = win[s + j];
+      idv[it] = idin[s + j];
       const uint64_t top = bucket_key ? (uint64_t)bucket_key[w >> top_shift] : (w >> top_shift);
       const uint64_t v = top_shift >= 64 ? w : ((top << top_shift) | (w & field_mask));
       wv[it] = v;
@@ -786,6 +807,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
     mx = b > mx ? b : mx;
   }
   if (lane == 0) { red_min[wave] = mn; red_max[wave] = mx; }
+  for (int i = tid; i < NW * 256; i += NT) aux[i] = 0;
   __syncthreads();
   mn = red_min[0]; mx = red_max[0];
   for (int i = 1; i < NW; ++i) {
@@ -795,92 +817,209 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
   const uint64_t low_mask = (1ull << low_bits) - 1;
   const uint64_t wmin = mn & ~low_mask;
   // bits in which the tile's words differ, above the low bits that are carried but not compared
+  const uint64_t range = (mx - wmin) >> low_bits;
   int span = 0;
-  for (uint64_t d = (mx - wmin) >> low_bits; d; d >>= 1) ++span;
+  for (uint64_t d = range; d; d >>= 1) ++span;
   if (span + low_bits + TS_IDX_BITS > 64) {  // no room for the slot number next to the word
     if (tid == 0) atomicOr(fallback, 1);
     return;
   }
+  // from here on a slot is (word - wmin) << TS_IDX_BITS | slot number: all distinct, and their
+  // order is the stable order of the words
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int j = wave * chunk + it * 64 + lane;
-    if (it < nit && j < m) sbuf[j] = ((wv[it] - wmin) << TS_IDX_BITS) | (uint64_t)j;
+    wv[it] = ((wv[it] - wmin) << TS_IDX_BITS) | (uint64_t)j;
   }
-  int passes = (span + 7) / 8;
-  if (passes > dbg_max_passes) passes = dbg_max_passes;
-#pragma unroll 1
-  for (int p = 0; p < passes; ++p) {
-    const int shift = TS_IDX_BITS + low_bits + 8 * p;
-    for (int i = tid; i < NW * 256; i += NT) (&whist[0][0])[i] = 0;
-    __syncthreads();  // also orders the previous pass's (or the initial) writes of sbuf before the reads
-    // rank of every slot among the slots of its wave with the same digit; only the digit is read
-    // here, the words stay in LDS until the scatter, so few registers are live while ranking
-    uint32_t rk[NI];  // rank | digit << 16, then the slot's destination
+  bool dense = force_radix != 0;
+  if (!dense && span > 0) {
+    // ---- interpolation placement: bin = floor(TS_BINS * value / (range + 1)) is monotone in the
+    // value; where the values are spread evenly a bin holds a slot or two.  Count per bin, scan,
+    // drop every slot into its bin (any order), then rank it among the slots of its bin.
+    const double scale = (double)TS_BINS / ((double)range + 1.0);
+    const int val_shift = TS_IDX_BITS + low_bits;
+    const uint64_t cmp_mask = ~(low_mask << TS_IDX_BITS);
+    uint32_t q[NI];
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-      rk[it] = 0;
-      if (it < nit) {  // wave-uniform
-        const int j = wave * chunk + it * 64 + lane;
-        const bool valid = j < m;
-        const uint32_t d = valid ? (uint32_t)(sbuf[j] >> shift) & 255u : 0u;
-        const uint64_t vb = __ballot(valid);
-        uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
-          const uint64_t bal = __ballot(mb != 0u);
-          plo &= ~((uint32_t)bal ^ mb);
-          phi &= ~((uint32_t)(bal >> 32) ^ mb);
-        }
-        const uint64_t peers = ((uint64_t)phi << 32) | plo;
-        uint32_t prior = __hip_atomic_load(&whist[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        const uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
-        const bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
-        if (leader)
-          __hip_atomic_store(&whist[wave][d], prior + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        rk[it] = (prior + (uint32_t)__popcll(peers & lt_mask)) | (d << 16);
+      const int j = wave * chunk + it * 64 + lane;
+      q[it] = 0;
+      if (it < nit && j < m) {
+        uint32_t b = (uint32_t)((double)(wv[it] >> val_shift) * scale);
+        b = b < (uint32_t)(TS_BINS - 1) ? b : (uint32_t)(TS_BINS - 1);
+        q[it] = b;
+        atomicAdd(&aux[b >> 1], 1u << ((b & 1u) * 16));
       }
     }
     __syncthreads();
-    uint32_t cnt_d = 0, cnt_inc = 0;
-    if (tid < 256) {
-      for (int w = 0; w < NW; ++w) {
-        const uint32_t c = whist[w][tid];
-        whist[w][tid] = cnt_d;
-        cnt_d += c;
+    {
+      // exclusive scan over the bins: thread t owns the TS_BINS / NT bins of aux[t * W .. t * W + W)
+      constexpr int W = TS_BINS / 2 / NT;  // words per thread
+      uint32_t c[2 * W];
+      uint32_t tot = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const uint32_t pkd = aux[tid * W + k];
+        c[2 * k] = pkd & 0xffffu;
+        c[2 * k + 1] = pkd >> 16;
+        tot += c[2 * k] + c[2 * k + 1];
       }
-      uint32_t inc = cnt_d;
+      uint32_t inc = tot;
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t tt = __shfl_up(inc, o, 64);
         if (lane >= o) inc += tt;
       }
       if (lane == 63) wtot[wave] = inc;
-      cnt_inc = inc;
+      __syncthreads();
+      uint32_t run = inc - tot;
+      for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const uint32_t a0 = run;
+        run += c[2 * k];
+        const uint32_t a1 = run;
+        run += c[2 * k + 1];
+        aux[tid * W + k] = a0 | (a1 << 16);
+      }
     }
     __syncthreads();
-    if (tid < 256) {
-      uint32_t wp = 0;
-      for (int w = 0; w < wave; ++w) wp += wtot[w];
-      dstart[tid] = wp + cnt_inc - cnt_d;
-    }
-    __syncthreads();
-    // in place: every slot is taken into registers before any slot is rewritten
+    // drop: the bin's counter hands out its slots and ends up at the bin's end (= the next bin's start)
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int j = wave * chunk + it * 64 + lane;
       if (it < nit && j < m) {
-        const uint32_t d = rk[it] >> 16;
-        wv[it] = sbuf[j];
-        rk[it] = dstart[d] + whist[wave][d] + (rk[it] & 0xffffu);
+        const uint32_t sh = (q[it] & 1u) * 16;
+        const uint32_t old = atomicAdd(&aux[q[it] >> 1], 1u << sh);
+        sbuf[(old >> sh) & 0xffffu] = wv[it];
       }
     }
+    __syncthreads();
+    bool crowded = false;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      if (it < nit && j < m) {
+        const uint32_t b = q[it];
+        const uint32_t hi = (aux[b >> 1] >> ((b & 1u) * 16)) & 0xffffu;
+        const uint32_t lo = b ? (aux[(b - 1) >> 1] >> (((b - 1) & 1u) * 16)) & 0xffffu : 0u;
+        uint32_t pos = lo;
+        if (hi - lo > (uint32_t)TS_DENSE) {
+          crowded = true;
+        } else {
+          // (value, slot number) decides; the carried low bits in between must not
+          const uint64_t mine = wv[it] & cmp_mask;
+          for (uint32_t t = lo; t < hi; ++t) pos += (sbuf[t] & cmp_mask) < mine ? 1u : 0u;
+        }
+        q[it] = pos;
+      }
+    }
+    if (__any(crowded) && lane == 0) dense_s = 1;
+    __syncthreads();
+    dense = dense_s != 0;
+    if (!dense) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = wave * chunk + it * 64 + lane;
+        if (it < nit && j < m) sbuf[q[it]] = wv[it];
+      }
+    }
+  }
+  if (dense || span == 0) {
+    // ---- radix passes (values bunched inside the tile, or nothing to sort: one plain copy)
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int j = wave * chunk + it * 64 + lane;
-      if (it < nit && j < m) sbuf[rk[it]] = wv[it];
+      if (it < nit && j < m) sbuf[j] = wv[it];
     }
-    __syncthreads();  // the counters are cleared for the next pass only after every slot has used them
+    const int passes = (span + 7) / 8;
+#pragma unroll 1
+    for (int p = 0; p < passes; ++p) {
+      const int shift = TS_IDX_BITS + low_bits + 8 * p;
+      __syncthreads();
+      for (int i = tid; i < NW * 256; i += NT) aux[i] = 0;
+      __syncthreads();  // also orders the previous pass's (or the initial) writes of sbuf before the reads
+      // rank of every slot among the slots of its wave with the same digit; only the digit is read
+      // here, the words stay in LDS until the scatter, so few registers are live while ranking
+      uint32_t rk[NI];  // rank | digit << 16, then the slot's destination
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        rk[it] = 0;
+        if (it < nit) {  // wave-uniform
+          const int j = wave * chunk + it * 64 + lane;
+          const bool valid = j < m;
+          const uint32_t d = valid ? (uint32_t)(sbuf[j] >> shift) & 255u : 0u;
+          const uint64_t vb = __ballot(valid);
+          uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
+            const uint64_t bal = __ballot(mb != 0u);
+            plo &= ~((uint32_t)bal ^ mb);
+            phi &= ~((uint32_t)(bal >> 32) ^ mb);
+          }
+          const uint64_t peers = ((uint64_t)phi << 32) | plo;
+          uint32_t prior = __hip_atomic_load(&whist[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+          const bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
+          if (leader)
+            __hip_atomic_store(&whist[wave][d], prior + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          rk[it] = (prior + (uint32_t)__popcll(peers & lt_mask)) | (d << 16);
+        }
+      }
+      __syncthreads();
+      uint32_t cnt_d = 0, cnt_inc = 0;
+      if (tid < 256) {
+        for (int w = 0; w < NW; ++w) {
+          const uint32_t c = whist[w][tid];
+          whist[w][tid] = cnt_d;
+          cnt_d += c;
+        }
+        uint32_t inc = cnt_d;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t tt = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += tt;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        cnt_inc = inc;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; ++w) wp += wtot[w];
+        dstart[tid] = wp + cnt_inc - cnt_d;
+      }
+      __syncthreads();
+      // in place: every slot is taken into registers before any slot is rewritten
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = wave * chunk + it * 64 + lane;
+        if (it < nit && j < m) {
+          const uint32_t d = rk[it] >> 16;
+          wv[it] = sbuf[j];
+          rk[it] = dstart[d] + whist[wave][d] + (rk[it] & 0xffffu);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = wave * chunk + it * 64 + lane;
+        if (it < nit && j < m) sbuf[rk[it]] = wv[it];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- out: words in order; the row ids change places through the same buffer
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int j = tid + it * NT;
+    wv[it] = j < m ? sbuf[j] : 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int j = wave * chunk + it * 64 + lane;
+    if (it < nit && j < m) sbuf32[j] = idv[it];
   }
   __syncthreads();
   const uint64_t idx_mask = (1ull << TS_IDX_BITS) - 1;
@@ -888,9 +1027,9 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
   for (int it = 0; it < NI; ++it) {
     const int j = tid + it * NT;
     if (j < m) {
-      const uint64_t pk = sbuf[j];
+      const uint64_t pk = wv[it];
       wout[s + j] = (pk >> TS_IDX_BITS) + wmin;
-      const uint32_t id = idin[s + (int64_t)(pk & idx_mask)];
+      const uint32_t id = sbuf32[(uint32_t)(pk & idx_mask)];
       idout[s + j] = id;
 #pragma unroll
       for (int c = 0; c < kMaxPay; ++c)
@@ -925,6 +1064,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
   b->key_rows = nullptr;
   b->key_nb = b->key_base = b->bucket_key = nullptr;
   b->fallback = nullptr;
+  b->tile_bounds = nullptr;
   b->max_buckets = 0;
   b->run_if = nullptr;
   const BucketGeom g = bucket_geometry(n, n_keys);
@@ -934,6 +1074,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
     b->key_base = ws.take<uint32_t>((size_t)n_keys);
     b->bucket_key = ws.take<uint32_t>((size_t)g.max_buckets);
     b->fallback = ws.take<int32_t>(1);
+    b->tile_bounds = ws.take<int64_t>((size_t)(n / TS_TILE + 3));
     b->max_buckets = g.max_buckets;
   }
 }
@@ -1182,11 +1323,14 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   TMP_REQUIRE(n_pay <= kMaxPay, TMP_EUNSUPPORTED, "ordering: at most %d payload column(s) per call", kMaxPay);
   pp.n = n_pay;
   for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
+  const int64_t n_tiles = (s.n + TS_TILE - 1) / TS_TILE;
+  TMP_LAUNCH(tile_bounds_kernel, dim3((unsigned)((n_tiles + 1 + 3) / 4)), dim3(kBlock), st, b.comp[at], s.n,
+             lay.key_shift(), TS_TILE, TS_CAP, n_tiles, b.tile_bounds);
   {
     ProfScope ps("tile_sort_kernel", st);
-    hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS>), dim3((unsigned)((s.n + TS_TILE - 1) / TS_TILE)),
-                       dim3(TS_THREADS), 0, st, b.comp[at], b.idx[at], b.comp[at ^ 1], b.idx[at ^ 1], s.n,
-                       lay.key_shift(), lay.low_bits, b.bucket_key, b.fallback, pp, getenv("TEMPO_DBG_PASSES") ? atoi(getenv("TEMPO_DBG_PASSES")) : 64);
+    hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS>), dim3((unsigned)n_tiles), dim3(TS_THREADS), 0, st,
+                       b.comp[at], b.idx[at], b.comp[at ^ 1], b.idx[at ^ 1], s.n, lay.key_shift(), lay.low_bits,
+                       b.bucket_key, b.tile_bounds, b.fallback, pp, getenv("TEMPO_TILE_RADIX") ? 1 : 0);
   }
   TMP_CHECK_HIP(hipGetLastError());
   // ---- stand-by: the plain passes, every kernel of which returns at once unless a tile gave up
