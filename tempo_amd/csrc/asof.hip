@@ -214,6 +214,10 @@ struct JoinCols {
   uint8_t *out_valid[TMP_MAX_JOIN_COLS];
   int8_t rule[TMP_MAX_JOIN_COLS];   // -1: last visible row; m: last visible row with mask m valid
   int8_t vmask[TMP_MAX_JOIN_COLS];  // -1: never NULL once matched; m: NULL where mask m is 0
+  // slot[c] >= 0: word of the right payload record that holds column c; -1: the column is the
+  // right table's own time column, whose values the ordered sort words already carry
+  int8_t slot[TMP_MAX_JOIN_COLS];
+  int n_rec;                        // columns held in the records
 };
 
 struct PackCols {
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *rr = nullptr;
     uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (jc.n) {
-      if (jrow >= 0) {
+      if (jrow >= 0 && jc.n_rec > 0) {
         if (row_src < 0) row_src = (int32_t)perm_r[jrow];
         rr = jc.rrec + (size_t)(uint32_t)row_src * jc.rstride;
         if (jc.rstride == 1) q0 = rr[0];
@@ -344,7 +348,9 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       for (int c = 0; c < jc.n; ++c) {  // columns that follow the row rule
         if (jc.rule[c] >= 0) continue;
         bool okv = jrow >= 0 && (jc.vmask[c] < 0 || ((wr_row >> jc.vmask[c]) & 1ull));
-        uint64_t v = c == 0 ? q0 : c == 1 ? q1 : c == 2 ? q2 : c == 3 ? q3 : (rr ? rr[c] : 0ull);
+        const int sl = jc.slot[c];
+        uint64_t v = sl < 0 ? (uint64_t)lay.prim_of(wr_row)
+                            : (sl == 0 ? q0 : sl == 1 ? q1 : sl == 2 ? q2 : sl == 3 ? q3 : (rr ? rr[sl] : 0ull));
         jc.out[c][dst] = okv ? v : 0ull;
         if (jc.out_valid[c]) jc.out_valid[c][dst] = okv ? 1 : 0;
       }
@@ -378,11 +384,14 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
         bool okv = jm >= 0 && (jc.vmask[c] < 0 || ((wm >> jc.vmask[c]) & 1ull));
         uint64_t v = 0;
         if (okv) {
-          if (jm == jrow) {
-            v = c == 0 ? q0 : c == 1 ? q1 : c == 2 ? q2 : c == 3 ? q3 : rr[c];
+          const int sl = jc.slot[c];
+          if (sl < 0) {
+            v = (uint64_t)lay.prim_of(wm);
+          } else if (jm == jrow) {
+            v = sl == 0 ? q0 : sl == 1 ? q1 : sl == 2 ? q2 : sl == 3 ? q3 : rr[sl];
           } else {
             if (!rm) rm = jc.rrec + (size_t)perm_r[jm] * jc.rstride;
-            v = rm[c];
+            v = rm[sl];
           }
         }
         jc.out[c][dst] = v;
@@ -408,14 +417,18 @@ __global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
 }
 
 static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
-  order_plan(a->n_left, ws, &p->lb, plan_keys(a->key_left, a->n_keys));
+  // one left payload column travels with the rows through the ordering passes
+  order_plan(a->n_left, ws, &p->lb, plan_keys(a->key_left, a->n_keys), a->sorted_output && a->n_left_cols == 1);
   order_plan(a->n_right, ws, &p->rb, plan_keys(a->key_right, a->n_keys));
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());
   const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
   p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
-  p->rrec = ws.take<uint64_t>(nrc >= 2 ? (size_t)rec_stride(nrc) * (size_t)a->n_right : 2);
+  int nrec = 0;  // right payload columns other than the right table's own time column
+  for (int c = 0; c < nrc; ++c)
+    if (a->right_cols && a->right_cols[c] != (const void *)a->ts_right) ++nrec;
+  p->rrec = ws.take<uint64_t>(nrec >= 2 ? (size_t)rec_stride(nrec) * (size_t)a->n_right : 2);
 }
 
 }  // namespace tmp
@@ -513,18 +526,13 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   OrderSpec lay_spec = rs;  // the key field exists if either side carries keys (one may be empty)
   if (!lay_spec.key) lay_spec.key = ls.key;
   TMP_TRY(order_make_layout(lay_spec, both, a->n_masks, &lay));
-  OrderResult lo, ro;
-  TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
-  TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
-
-  // payload columns of the fused join: packed into row records when a side has several
+  // payload columns of the fused join
   const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
   JoinCols jc;
   memset(&jc, 0, sizeof(jc));
   jc.n_left = nlc;
   jc.n = a->n_right > 0 ? nrc : 0;
   jc.lstride = rec_stride(nlc);
-  jc.rstride = rec_stride(nrc);
   PackCols pl, pr;
   memset(&pl, 0, sizeof(pl));
   memset(&pr, 0, sizeof(pr));
@@ -533,29 +541,51 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     pl.src[c] = (const uint64_t *)a->left_cols[c];
     jc.lout[c] = (uint64_t *)a->out_left_cols[c];
   }
+  int nrec = 0;
   for (int c = 0; c < nrc; ++c) {
     TMP_REQUIRE(a->n_right == 0 || a->right_cols[c], TMP_EINVAL, "tmp_asof_join: right payload column %d is null", c);
     TMP_REQUIRE(a->out_right_cols[c], TMP_EINVAL, "tmp_asof_join: right output column %d is null", c);
-    pr.src[c] = (const uint64_t *)a->right_cols[c];
     jc.out[c] = (uint64_t *)a->out_right_cols[c];
     jc.out_valid[c] = a->out_right_valid[c];
     jc.rule[c] = (int8_t)a->right_col_rule[c];
     jc.vmask[c] = (int8_t)a->right_col_valid[c];
+    if (a->right_cols[c] == (const void *)a->ts_right) {
+      jc.slot[c] = -1;  // the right time column itself: read off the ordered sort words
+    } else {
+      jc.slot[c] = (int8_t)nrec;
+      pr.src[nrec++] = (const uint64_t *)a->right_cols[c];
+    }
   }
+  jc.n_rec = nrec;
+  jc.rstride = rec_stride(nrec);
   if (nrc > 0 && a->n_right == 0) {  // nothing to match: every joined column is NULL
     for (int c = 0; c < nrc; ++c) {
       TMP_CHECK_HIP(hipMemsetAsync(a->out_right_cols[c], 0, sizeof(uint64_t) * a->n_left, st));
       if (a->out_right_valid[c]) TMP_CHECK_HIP(hipMemsetAsync(a->out_right_valid[c], 0, a->n_left, st));
     }
   }
+  OrderResult lo, ro;
+  // a single left payload column is handed to the ordering step, which delivers it in (key, ts)
+  // order straight into the output column; where it could not (rows already in order: no pass
+  // ran) the merge fetches it through the row ids as it does for several columns
+  bool left_delivered = false;
+  if (nlc == 1) {
+    const uint64_t *src1[1] = {pl.src[0]};
+    uint64_t *out1[1] = {jc.lout[0]};
+    TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st, 1, src1, out1, &left_delivered));
+  } else {
+    TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
+  }
+  if (left_delivered) jc.n_left = 0;
+  TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
   jc.lrec = nlc == 1 ? pl.src[0] : p.lrec;
-  jc.rrec = nrc == 1 ? pr.src[0] : p.rrec;
+  jc.rrec = nrec == 1 ? pr.src[0] : p.rrec;
   if (nlc >= 2) {
     pl.n = nlc; pl.stride = jc.lstride;
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_left * (jc.lstride / 2), kBlock, 8192)), dim3(kBlock), st, pl, a->n_left, p.lrec);
   }
-  if (nrc >= 2 && a->n_right > 0) {
-    pr.n = nrc; pr.stride = jc.rstride;
+  if (nrec >= 2 && a->n_right > 0) {
+    pr.n = nrec; pr.stride = jc.rstride;
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right * (jc.rstride / 2), kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
   }
 

@@ -133,6 +133,7 @@ struct OrderBuffers {
   int64_t *tile_bounds;          // [tiles + 1] first bucket start at or after every tile's first row
   int64_t max_buckets;
   const int32_t *run_if;         // host-side switch: non-null while the stand-by passes are enqueued
+  uint64_t *carry[2];            // ping-pong copies of one payload column that travels with the rows
 };
 
 struct OrderResult {
@@ -141,7 +142,8 @@ struct OrderResult {
 };
 
 // n_keys > 0 also reserves what the bucketed ordering of a large table needs.
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys = 0);
+// carry: also two row-sized buffers for a payload column that moves with the rows in every pass.
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys = 0, bool carry = false);
 // Size of the key dictionary as the ordering step sees it (a table without keys is one series).
 inline int64_t plan_keys(const void *key, int64_t n_keys) { return key ? (n_keys > 0 ? n_keys : 1) : 1; }
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st);
@@ -154,6 +156,7 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 constexpr int kMaxPay = 1;
 struct PayPtrs {
   int n;
+  int positional;  // src is already in the order of the rows being moved (src[position], not src[row id])
   const uint64_t *src[kMaxPay];
   uint64_t *out[kMaxPay];
 };

@@ -270,11 +270,12 @@ static SortGeom sort_geom(int64_t n, int tile) {
 // them to `words`; the row ids of a first pass are the positions and are never stored).
 // GEN == 2: the words also take the row id into their low gen.id_bits bits.
 template <int RS_THREADS, int RS_ITEMS, int RS_BITS, int GEN>
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *keys, int64_t n,
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *__restrict__ keys, int64_t n,
                                                                 int shift, uint32_t mask,
                                                                 int tiles_per_block,
-                                                                uint32_t *counts, GenArgs gen,
-                                                                uint64_t *words, const int32_t *run_if) {
+                                                                uint32_t *__restrict__ counts, GenArgs gen,
+                                                                uint64_t *__restrict__ words,
+                                                                const int32_t *run_if) {
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
   constexpr int RS_WAVES = RS_THREADS / 64;
   constexpr int RS_RADIX = 1 << RS_BITS;
@@ -286,17 +287,32 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
   int64_t end = begin + (int64_t)tiles_per_block * RS_TILE;
   if (end > n) end = n;
   int wave = threadIdx.x >> 6;
-  for (int64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
-    uint64_t w;
-    if (GEN) {
-      w = make_word(gen, i);
-      if (GEN == 2) w = (w << gen.id_bits) | (uint64_t)i;
-      words[i] = w;
-    } else {
-      w = keys[i];
+  // four rows per thread and round: all their loads are issued before the first store or counter
+  // update, so a wave keeps four requests per column in flight instead of one
+  constexpr int UN = 4;
+  for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += (int64_t)UN * RS_THREADS) {
+    uint64_t w[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i = i0 + (int64_t)u * RS_THREADS;
+      w[u] = 0;
+      if (i < end) {
+        if (GEN) {
+          w[u] = make_word(gen, i);
+          if (GEN == 2) w[u] = (w[u] << gen.id_bits) | (uint64_t)i;
+        } else {
+          w[u] = keys[i];
+        }
+      }
     }
-    uint32_t d = (uint32_t)(w >> shift) & mask;
-    atomicAdd(&hist[wave][d], 1u);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i = i0 + (int64_t)u * RS_THREADS;
+      if (i < end) {
+        if (GEN) words[i] = w[u];
+        atomicAdd(&hist[wave][(uint32_t)(w[u] >> shift) & mask], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
@@ -389,7 +405,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
     PayPtrs pp, int id_bits, const int32_t *run_if) {
-  constexpr bool PAY = NPAY > 0;
+  // NPAY < 0: -NPAY columns that are already in the order of the rows being moved (read by
+  // position, no dependent load: the larger plain tile serves, nothing is requested ahead)
+  constexpr bool PAY = NPAY != 0;
+  constexpr bool POS = NPAY < 0;
+  constexpr int NP = NPAY < 0 ? -NPAY : NPAY;
   if (run_if && !*run_if) return;
   const uint64_t id_mask = PACK ? ((1ull << id_bits) - 1) : 0ull;
   constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
   // Payload passes read their payload through the row ids, a dependent chain of loads: there
   // the pairs of the next tile are requested one tile ahead.  Plain passes use the registers
   // for a larger tile instead.
-  constexpr bool PREFETCH = PAY;
+  constexpr bool PREFETCH = PAY && !POS;
   uint64_t k[RS_ITEMS], kn[PREFETCH ? RS_ITEMS : 1];
   uint32_t v[RS_ITEMS], vn[PREFETCH ? RS_ITEMS : 1];
   if (PREFETCH) {
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     int tile_n = (int)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
     for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) whist[i / RS_RADIX][i % RS_RADIX] = 0;
     __syncthreads();
-    uint64_t pay[PAY ? NPAY : 1][PAY ? RS_ITEMS : 1];
+    uint64_t pay[PAY ? NP : 1][PAY ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
     if (PREFETCH) {
@@ -460,12 +480,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         k[it] = pos < tile_n ? kin[tile_base + pos] : 0ull;
       }
     }
-    if (PAY) {
+    if (PAY && !POS) {
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
         int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < NPAY; ++c)
+        for (int c = 0; c < NP; ++c)
           pay[c][PAY ? it : 0] = (pos < tile_n && c < pp.n) ? pp.src[c][v[it]] : 0ull;
       }
     }
@@ -556,7 +576,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
         int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-        if (!PAY) v[it] = pos < tile_n ? (FIRST ? (uint32_t)(tile_base + pos) : vin[tile_base + pos]) : 0u;
+        if (!PREFETCH) v[it] = pos < tile_n ? (FIRST ? (uint32_t)(tile_base + pos) : vin[tile_base + pos]) : 0u;
       }
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
@@ -572,8 +592,15 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     }
     if (PAY) {
 #pragma unroll
-      for (int c = 0; c < NPAY; ++c) {
+      for (int c = 0; c < NP; ++c) {
         if (c < pp.n) {  // uniform
+          if (POS) {  // read only now, by position: nothing of it was live while the tile was ranked
+#pragma unroll
+            for (int it = 0; it < RS_ITEMS; ++it) {
+              int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+              pay[c][PAY ? it : 0] = pos < tile_n ? pp.src[c][tile_base + pos] : 0ull;
+            }
+          }
           __syncthreads();
 #pragma unroll
           for (int it = 0; it < RS_ITEMS; ++it) {
@@ -1033,7 +1060,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
       idout[s + j] = id;
 #pragma unroll
       for (int c = 0; c < kMaxPay; ++c)
-        if (c < pp.n) pp.out[c][s + j] = pp.src[c][id];
+        if (c < pp.n) pp.out[c][s + j] = pp.src[c][pp.positional ? (uint64_t)(s + (int64_t)(pk & idx_mask)) : (uint64_t)id];
     }
   }
 }
@@ -1053,7 +1080,7 @@ __global__ void copy_pairs_if_kernel(const uint64_t *win, const uint32_t *idin, 
 // ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, bool carry) {
   size_t cnt = (size_t)(n > 0 ? n : 1);
   b->comp[0] = ws.take<uint64_t>(cnt);
   b->comp[1] = ws.take<uint64_t>(cnt);
@@ -1067,6 +1094,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
   b->tile_bounds = nullptr;
   b->max_buckets = 0;
   b->run_if = nullptr;
+  b->carry[0] = b->carry[1] = nullptr;
   const BucketGeom g = bucket_geometry(n, n_keys);
   if (g.ok) {
     b->key_rows = ws.take<unsigned long long>((size_t)n_keys);
@@ -1076,6 +1104,10 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys) {
     b->fallback = ws.take<int32_t>(1);
     b->tile_bounds = ws.take<int64_t>((size_t)(n / TS_TILE + 3));
     b->max_buckets = g.max_buckets;
+    if (carry) {
+      b->carry[0] = ws.take<uint64_t>(cnt);
+      b->carry[1] = ws.take<uint64_t>(cnt);
+    }
   }
 }
 
@@ -1160,10 +1192,10 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
     ProfScope ps(gen ? "radix_hist_kernel+words" : "radix_hist_kernel", st);
     if (gen && gen->id_bits)
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 2>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
+                         (const uint64_t *)nullptr, n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
     else if (gen)
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 1>), dim3(g.grid), dim3(THREADS), 0, st,
-                         b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
+                         (const uint64_t *)nullptr, n, shift, mask, g.tiles_per_block, b.counts, *gen, b.comp[cur], b.run_if);
     else
       hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 0>), dim3(g.grid), dim3(THREADS), 0, st,
                          b.comp[cur], n, shift, mask, g.tiles_per_block, b.counts, none, (uint64_t *)nullptr, b.run_if);
@@ -1171,7 +1203,7 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
   }
   {
     ProfScope ps(NPAY == 0 ? (pack ? "radix_scatter_kernel+ids_in_words" : "radix_scatter_kernel")
-                           : "radix_scatter_kernel+payload", st);
+                           : (NPAY < 0 ? "radix_scatter_kernel+carried" : "radix_scatter_kernel+payload"), st);
     const bool first = gen != nullptr;
     if (pack == 2)
       radix_scatter_launch<THREADS, ITEMS, NPAY, BITS, 2>(b, n, cur, shift, mask, nbits, st, pp, first, g, id_bits);
@@ -1200,7 +1232,8 @@ static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbit
 // identity and the outputs are untouched).
 static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
                         hipStream_t st, int n_pay, const uint64_t *const *pay_src,
-                        uint64_t *const *pay_out, bool *carried, const GenArgs *gen) {
+                        uint64_t *const *pay_out, bool *carried, const GenArgs *gen,
+                        uint64_t *const *carry_buf = nullptr, int *carry_at = nullptr) {
   int cur = 0;
   if (carried) *carried = false;
   PayPtrs none;
@@ -1225,7 +1258,18 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
     bool last = p + 1 == passes;
     const GenArgs *g = p == 0 ? (packed ? &gen_packed : gen) : nullptr;
     const int pack = packed ? (last ? 2 : 1) : 0;
-    if (last && n_pay > 0) {
+    if (carry_buf) {
+      // the payload column moves with the rows in every pass: read where the rows are read,
+      // written where they are written
+      PayPtrs pp;
+      memset(&pp, 0, sizeof(pp));
+      pp.n = 1;
+      pp.positional = 1;
+      pp.src[0] = p == 0 ? pay_src[0] : carry_buf[(p - 1) & 1];
+      pp.out[0] = carry_buf[p & 1];
+      radix_one_pass<1024, 12, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
+      if (carry_at) *carry_at = p & 1;
+    } else if (last && n_pay > 0) {
       for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
         PayPtrs pp;
         memset(&pp, 0, sizeof(pp));
@@ -1316,13 +1360,22 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   bgen.inv = rel_count <= 1 ? 0ull : (~0ull / rel_count) + 1;                                                // ceil(2^64 / R)
   // ---- partition passes over the bucket field, then the tiles
   OrderResult part;
-  TMP_TRY(radix_passes(b, s.n, lay.key_shift(), lay.key_shift() + bg.bits, &part, st, 0, nullptr, nullptr, nullptr, &bgen));
+  TMP_REQUIRE(n_pay <= kMaxPay, TMP_EUNSUPPORTED, "ordering: at most %d payload column(s) per call", kMaxPay);
+  // a payload column either travels with the rows through every partition pass (buffers planned
+  // for it: all its reads and writes stream) or is fetched through the row ids at the very end
+  const bool carry = n_pay == 1 && b.carry[0] && b.carry[1];
+  int carry_at = 0;
+  TMP_TRY(radix_passes(b, s.n, lay.key_shift(), lay.key_shift() + bg.bits, &part, st, carry ? 1 : 0,
+                       carry ? pay_src : nullptr, nullptr, nullptr, &bgen, carry ? b.carry : nullptr, &carry_at));
   const int at = part.comp == b.comp[0] ? 0 : 1;
   PayPtrs pp;
   memset(&pp, 0, sizeof(pp));
-  TMP_REQUIRE(n_pay <= kMaxPay, TMP_EUNSUPPORTED, "ordering: at most %d payload column(s) per call", kMaxPay);
   pp.n = n_pay;
   for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
+  if (carry) {
+    pp.positional = 1;
+    pp.src[0] = b.carry[carry_at];
+  }
   const int64_t n_tiles = (s.n + TS_TILE - 1) / TS_TILE;
   TMP_LAUNCH(tile_bounds_kernel, dim3((unsigned)((n_tiles + 1 + 3) / 4)), dim3(kBlock), st, b.comp[at], s.n,
              lay.key_shift(), TS_TILE, TS_CAP, n_tiles, b.tile_bounds);
