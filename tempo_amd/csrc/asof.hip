@@ -10,6 +10,7 @@
 //      narrowed per block), applies the key / bracket visibility tests and scatters the
 //      matched right row ids back to the left table's own row order, one record of
 //      (1 + masks) ids per left row so that the random write touches one line.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -23,6 +24,8 @@ struct AsofPlan {
   int32_t *unit_agg; // [n_masks][kUnits]
   uint64_t *lrec;    // [n_left][stride] packed left payload records (2+ columns)
   uint64_t *rrec;    // [n_right][stride] packed right payload records (2+ columns)
+  uint64_t *rsort[kMaxPay];  // right payload columns in sorted order (when the ordering step carries them)
+  int64_t *block_bounds;     // [merge blocks + 1]
 };
 
 // 8-byte words per packed payload record: a power of two up to 4 (so that a record never
@@ -218,6 +221,10 @@ struct JoinCols {
   // right table's own time column, whose values the ordered sort words already carry
   int8_t slot[TMP_MAX_JOIN_COLS];
   int n_rec;                        // columns held in the records
+  // rsorted: the ordering step delivered those columns in the order of the right side's sort
+  // words (rs[slot][position]); no records, no row ids
+  int rsorted;
+  const uint64_t *rs[kMaxPay];
 };
 
 struct PackCols {
@@ -249,8 +256,23 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(PackCols pc, int64_t 
   }
 }
 
-constexpr int kMergeRows = 4;     // left rows per thread
-constexpr int kMergeRight = 3072;  // right sort words staged in LDS per block
+// bounds[b] = number of right rows ordered at or before the first left row of merge block b
+// (b < n_blocks), bounds[n_blocks] = n_right: one thread per block, so that the 30-step searches
+// of all blocks run side by side instead of one per block at the head of its own work.
+__global__ __launch_bounds__(kBlock) void merge_bounds_kernel(const uint64_t *comp_l, int64_t n_left,
+                                                              const uint64_t *comp_r, int64_t n_right, int low_bits,
+                                                              int rows_per_block, int64_t n_blocks, int64_t *bounds) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_blocks) return;
+  if (b == n_blocks) { bounds[b] = n_right; return; }
+  bounds[b] = upper_bound(comp_r, 0, n_right, comp_l[b * rows_per_block] >> low_bits, low_bits);
+}
+
+#ifndef TEMPO_MERGE_ROWS
+#define TEMPO_MERGE_ROWS 2
+#endif
+constexpr int kMergeRows = TEMPO_MERGE_ROWS;     // left rows per thread
+constexpr int kMergeRight = 768 * kMergeRows;  // right sort words staged in LDS per block
 
 // Block = 1024 consecutive rows of the ordered left side.  Their positions in the ordered right
 // side all fall between the positions of the block's first and last row; that slice of right
@@ -259,23 +281,16 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
     SkewParams sp, int32_t *out_idx, int32_t *out_missing, int sorted_output, int32_t *out_perm,
-    int32_t *out_key, int64_t *out_ts, JoinCols jc) {
-  __shared__ int64_t bounds[2];
+    int32_t *out_key, int64_t *out_ts, JoinCols jc, const int64_t *block_bounds) {
   __shared__ uint64_t rw[kMergeRight];
   const int low = lay.low_bits;
   int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
   int64_t tile_end = tile + kBlock * kMergeRows < n_left ? tile + kBlock * kMergeRows : n_left;
-  // Waves 0 and 1 each find one end of the block's search range; every lane of the wave runs
-  // the same search (a wave-uniform branch), lane 0 publishes it.
-  const int wave = threadIdx.x >> 6;
-  if (wave < 2) {
-    uint64_t k = (wave == 0 ? comp_l[tile] : comp_l[tile_end - 1]) >> low;
-    int64_t ub = upper_bound(comp_r, 0, n_right, k, low);
-    if (wave == 0) ub = ub > 0 ? ub - 1 : 0;  // the row just before the first position stays reachable
-    if ((threadIdx.x & 63) == 0) bounds[wave] = ub;
-  }
-  __syncthreads();
-  const int64_t blo = bounds[0], bhi = bounds[1];
+  // The block's rows fall between the positions of its first row and of the next block's first
+  // row in the ordered right side (merge_bounds_kernel); the row just before the first position
+  // stays reachable.
+  const int64_t b0 = block_bounds[blockIdx.x];
+  const int64_t blo = b0 > 0 ? b0 - 1 : 0, bhi = block_bounds[blockIdx.x + 1];
   const bool staged = bhi - blo <= kMergeRight;  // block-uniform
   if (staged) {
     for (int e = threadIdx.x; e < (int)(bhi - blo); e += kBlock) rw[e] = comp_r[blo + e];
@@ -283,10 +298,23 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
   }
   int miss_row = 0;
   uint32_t miss_mask = 0;
+  // A row's work is a chain of dependent accesses; what does not depend on the chain is requested
+  // ahead of it: the left words and row ids of all of the thread's rows up front, and -- once a
+  // row's position in the right side is known -- its last-valid positions of the first four masks
+  // together with the payload of the row it matched.
+  uint64_t wl_pre[kMergeRows];
+  uint32_t src_pre[kMergeRows];
+#pragma unroll
+  for (int r = 0; r < kMergeRows; ++r) {
+    const int64_t i = tile + r * kBlock + threadIdx.x;
+    wl_pre[r] = i < tile_end ? comp_l[i] : 0ull;
+    src_pre[r] = i < tile_end ? perm_l[i] : 0u;
+  }
+#pragma unroll
   for (int r = 0; r < kMergeRows; ++r) {
     int64_t i = tile + r * kBlock + threadIdx.x;
     if (i >= tile_end) break;
-    uint64_t wl = comp_l[i];
+    uint64_t wl = wl_pre[r];
     uint64_t kl = wl >> low;
     int64_t pos;
     uint64_t wr_row = 0;
@@ -308,8 +336,12 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     bool same = jr >= blo && lay.key_of(wr_row) == key_l;
     double part_l = 0.0;
     if (sp.enabled) part_l = bracket_part(bracket_seconds(lay.prim_of(wl), sp), sp);
-    uint32_t src_row = perm_l[i];
+    uint32_t src_row = src_pre[r];
     uint32_t dst = sorted_output ? (uint32_t)i : src_row;
+    int32_t jpre[4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+      jpre[mm] = (same && mm < n_masks) ? lastnn[(size_t)mm * n_right + jr] : -1;
     if (sorted_output) {
       out_perm[i] = (int32_t)src_row;
       if (out_key) out_key[i] = (int32_t)key_l;
@@ -332,7 +364,12 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *rr = nullptr;
     uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (jc.n) {
-      if (jrow >= 0 && jc.n_rec > 0) {
+      if (jrow >= 0 && jc.n_rec > 0 && jc.rsorted) {
+        q0 = jc.rs[0][jrow];
+        if (jc.n_rec > 1) q1 = jc.rs[1][jrow];
+        if (jc.n_rec > 2) q2 = jc.rs[2][jrow];
+        if (jc.n_rec > 3) q3 = jc.rs[3][jrow];
+      } else if (jrow >= 0 && jc.n_rec > 0) {
         if (row_src < 0) row_src = (int32_t)perm_r[jrow];
         rr = jc.rrec + (size_t)(uint32_t)row_src * jc.rstride;
         if (jc.rstride == 1) q0 = rr[0];
@@ -359,7 +396,8 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       int64_t jm = -1;  // position of the last visible row whose mask m is valid, or -1
       uint64_t wm = 0;
       if (same) {
-        int32_t j = lastnn[(size_t)m * n_right + jr];
+        int32_t j = m == 0 ? jpre[0] : m == 1 ? jpre[1] : m == 2 ? jpre[2] : m == 3 ? jpre[3]
+                                                                  : lastnn[(size_t)m * n_right + jr];
         if (j >= 0) {
           // two typed loads, not one load through a pointer chosen at run time (that becomes
           // a flat access, which waits on every outstanding global and LDS operation)
@@ -389,6 +427,8 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
             v = (uint64_t)lay.prim_of(wm);
           } else if (jm == jrow) {
             v = sl == 0 ? q0 : sl == 1 ? q1 : sl == 2 ? q2 : sl == 3 ? q3 : rr[sl];
+          } else if (jc.rsorted) {
+            v = sl == 0 ? jc.rs[0][jm] : sl == 1 ? jc.rs[1][jm] : sl == 2 ? jc.rs[2][jm] : jc.rs[3][jm];
           } else {
             if (!rm) rm = jc.rrec + (size_t)perm_r[jm] * jc.rstride;
             v = rm[sl];
@@ -419,15 +459,23 @@ __global__ void fill_i32_kernel(int32_t *p, int64_t n, int32_t v) {
 static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
   // one left payload column travels with the rows through the ordering passes
   order_plan(a->n_left, ws, &p->lb, plan_keys(a->key_left, a->n_keys), a->sorted_output && a->n_left_cols == 1);
-  order_plan(a->n_right, ws, &p->rb, plan_keys(a->key_right, a->n_keys));
+  int nrec = 0;  // right payload columns other than the right table's own time column
+  for (int c = 0; c < (a->sorted_output ? a->n_right_cols : 0); ++c)
+    if (a->right_cols && a->right_cols[c] != (const void *)a->ts_right) ++nrec;
+  // Carrying the right payload through the right side's passes makes every access of the merge
+  // stream, but at today's pass rates it costs more than the merge's one random record read per
+  // row saves (5x10^8 + 5x10^8 rows, two 8-byte columns: join 80.1 ms with, 75.2 ms without).
+  // TEMPO_RIGHT_CARRY=1 switches it on for measurements.
+  const int rcarry = (nrec >= 1 && nrec <= kMaxPay && getenv("TEMPO_RIGHT_CARRY")) ? nrec : 0;
+  order_plan(a->n_right, ws, &p->rb, plan_keys(a->key_right, a->n_keys), rcarry);
+  for (int c = 0; c < kMaxPay; ++c)
+    p->rsort[c] = c < rcarry ? ws.take<uint64_t>((size_t)(a->n_right > 0 ? a->n_right : 1)) : nullptr;
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());
-  const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
+  p->block_bounds = ws.take<int64_t>((size_t)(a->n_left / (kBlock * kMergeRows) + 3));
+  const int nlc = a->sorted_output ? a->n_left_cols : 0;
   p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
-  int nrec = 0;  // right payload columns other than the right table's own time column
-  for (int c = 0; c < nrc; ++c)
-    if (a->right_cols && a->right_cols[c] != (const void *)a->ts_right) ++nrec;
   p->rrec = ws.take<uint64_t>(nrec >= 2 ? (size_t)rec_stride(nrec) * (size_t)a->n_right : 2);
 }
 
@@ -577,14 +625,25 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     TMP_TRY(order_build(ls, lay, sorted_mode(rl), p.lb, &lo, st));
   }
   if (left_delivered) jc.n_left = 0;
-  TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
+  // likewise the right payload columns (up to kMaxPay of them): delivered in the order of the right
+  // side's sort words, the merge then reads them by position; otherwise records fetched by row id
+  bool right_delivered = false;
+  if (nrec >= 1 && nrec <= kMaxPay && a->n_right > 0 && p.rsort[0]) {
+    TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st, nrec, pr.src, p.rsort, &right_delivered));
+  } else {
+    TMP_TRY(order_build(rs, lay, sorted_mode(rr), p.rb, &ro, st));
+  }
+  if (right_delivered) {
+    jc.rsorted = 1;
+    for (int c = 0; c < nrec; ++c) jc.rs[c] = p.rsort[c];
+  }
   jc.lrec = nlc == 1 ? pl.src[0] : p.lrec;
   jc.rrec = nrec == 1 ? pr.src[0] : p.rrec;
   if (nlc >= 2) {
     pl.n = nlc; pl.stride = jc.lstride;
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_left * (jc.lstride / 2), kBlock, 8192)), dim3(kBlock), st, pl, a->n_left, p.lrec);
   }
-  if (nrec >= 2 && a->n_right > 0) {
+  if (nrec >= 2 && a->n_right > 0 && !right_delivered) {
     pr.n = nrec; pr.stride = jc.rstride;
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right * (jc.rstride / 2), kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
   }
@@ -597,9 +656,11 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   sp.v = a->ts_partition_val;
   sp.one_minus_fraction = a->one_minus_fraction;
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
+  TMP_LAUNCH(merge_bounds_kernel, dim3((grid + 1 + kBlock - 1) / kBlock), dim3(kBlock), st, lo.comp, a->n_left, ro.comp,
+             a->n_right, lay.low_bits, kBlock * kMergeRows, (int64_t)grid, p.block_bounds);
   TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
                      ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc);
+                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

@@ -133,7 +133,8 @@ struct OrderBuffers {
   int64_t *tile_bounds;          // [tiles + 1] first bucket start at or after every tile's first row
   int64_t max_buckets;
   const int32_t *run_if;         // host-side switch: non-null while the stand-by passes are enqueued
-  uint64_t *carry[2];            // ping-pong copies of one payload column that travels with the rows
+  uint64_t *carry[2 * 4];        // [column][2] ping-pong copies of payload columns that travel with the rows
+  int carry_cols;
 };
 
 struct OrderResult {
@@ -142,8 +143,8 @@ struct OrderResult {
 };
 
 // n_keys > 0 also reserves what the bucketed ordering of a large table needs.
-// carry: also two row-sized buffers for a payload column that moves with the rows in every pass.
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys = 0, bool carry = false);
+// carry_cols: also two row-sized buffers per payload column that moves with the rows in every pass.
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys = 0, int carry_cols = 0);
 // Size of the key dictionary as the ordering step sees it (a table without keys is one series).
 inline int64_t plan_keys(const void *key, int64_t n_keys) { return key ? (n_keys > 0 ? n_keys : 1) : 1; }
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st);
@@ -153,7 +154,7 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
 // (primary, seq) order with interleaved keys (a time-ordered feed): the stable passes over the
 // key bits alone finish the job.
 // Payload columns that ride along with the last radix pass (8-byte elements).
-constexpr int kMaxPay = 1;
+constexpr int kMaxPay = 4;
 struct PayPtrs {
   int n;
   int positional;  // src is already in the order of the rows being moved (src[position], not src[row id])

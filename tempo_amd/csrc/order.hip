@@ -454,7 +454,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     int tile_n = (int)((n - tile_base) < RS_TILE ? (n - tile_base) : RS_TILE);
     for (int i = tid; i < RS_WAVES * RS_RADIX; i += RS_THREADS) whist[i / RS_RADIX][i % RS_RADIX] = 0;
     __syncthreads();
-    uint64_t pay[PAY ? NP : 1][PAY ? RS_ITEMS : 1];
+    uint64_t pay[(PAY && !POS) ? NP : 1][(PAY && !POS) ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
     if (PREFETCH) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NP; ++c)
-          pay[c][PAY ? it : 0] = (pos < tile_n && c < pp.n) ? pp.src[c][v[it]] : 0ull;
+          pay[c][(PAY && !POS) ? it : 0] = (pos < tile_n && c < pp.n) ? pp.src[c][v[it]] : 0ull;
       }
     }
 #pragma unroll
@@ -590,22 +590,15 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (p < tile_n) vout[gpos[j]] = sbuf32[p];
       }
     }
-    if (PAY) {
+    if (PAY && !POS) {
 #pragma unroll
       for (int c = 0; c < NP; ++c) {
         if (c < pp.n) {  // uniform
-          if (POS) {  // read only now, by position: nothing of it was live while the tile was ranked
-#pragma unroll
-            for (int it = 0; it < RS_ITEMS; ++it) {
-              int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-              pay[c][PAY ? it : 0] = pos < tile_n ? pp.src[c][tile_base + pos] : 0ull;
-            }
-          }
           __syncthreads();
 #pragma unroll
           for (int it = 0; it < RS_ITEMS; ++it) {
             int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-            if (pos < tile_n) sbuf[rank[it]] = pay[c][PAY ? it : 0];
+            if (pos < tile_n) sbuf[rank[it]] = pay[c][(PAY && !POS) ? it : 0];
           }
           __syncthreads();
 #pragma unroll
@@ -613,6 +606,33 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
             int p = tid + j * RS_THREADS;
             if (p < tile_n) pp.out[c][gpos[j]] = sbuf[p];
           }
+        }
+      }
+    }
+    if (POS) {
+      // columns that travel with the rows: each is read by position only now (nothing of it was
+      // live while the tile was ranked) and goes through the staging buffer like the words did
+#pragma unroll 1
+      for (int c = 0; c < pp.n; ++c) {
+        const uint64_t *src = pp.src[c];
+        uint64_t *out = pp.out[c];
+        uint64_t pv[RS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+          int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+          pv[it] = pos < tile_n ? src[tile_base + pos] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+          int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+          if (pos < tile_n) sbuf[rank[it]] = pv[it];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+          int p = tid + j * RS_THREADS;
+          if (p < tile_n) out[gpos[j]] = sbuf[p];
         }
       }
     }
@@ -1058,9 +1078,10 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
       wout[s + j] = (pk >> TS_IDX_BITS) + wmin;
       const uint32_t id = sbuf32[(uint32_t)(pk & idx_mask)];
       idout[s + j] = id;
+      const uint64_t from = pp.positional ? (uint64_t)(s + (int64_t)(pk & idx_mask)) : (uint64_t)id;
 #pragma unroll
       for (int c = 0; c < kMaxPay; ++c)
-        if (c < pp.n) pp.out[c][s + j] = pp.src[c][pp.positional ? (uint64_t)(s + (int64_t)(pk & idx_mask)) : (uint64_t)id];
+        if (c < pp.n) pp.out[c][s + j] = pp.src[c][from];
     }
   }
 }
@@ -1080,7 +1101,7 @@ __global__ void copy_pairs_if_kernel(const uint64_t *win, const uint32_t *idin, 
 // ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
-void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, bool carry) {
+void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, int carry_cols) {
   size_t cnt = (size_t)(n > 0 ? n : 1);
   b->comp[0] = ws.take<uint64_t>(cnt);
   b->comp[1] = ws.take<uint64_t>(cnt);
@@ -1094,7 +1115,8 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, bool 
   b->tile_bounds = nullptr;
   b->max_buckets = 0;
   b->run_if = nullptr;
-  b->carry[0] = b->carry[1] = nullptr;
+  b->carry_cols = 0;
+  for (int c = 0; c < 2 * kMaxPay; ++c) b->carry[c] = nullptr;
   const BucketGeom g = bucket_geometry(n, n_keys);
   if (g.ok) {
     b->key_rows = ws.take<unsigned long long>((size_t)n_keys);
@@ -1104,10 +1126,8 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, bool 
     b->fallback = ws.take<int32_t>(1);
     b->tile_bounds = ws.take<int64_t>((size_t)(n / TS_TILE + 3));
     b->max_buckets = g.max_buckets;
-    if (carry) {
-      b->carry[0] = ws.take<uint64_t>(cnt);
-      b->carry[1] = ws.take<uint64_t>(cnt);
-    }
+    b->carry_cols = carry_cols < kMaxPay ? carry_cols : kMaxPay;
+    for (int c = 0; c < 2 * b->carry_cols; ++c) b->carry[c] = ws.take<uint64_t>(cnt);
   }
 }
 
@@ -1263,17 +1283,20 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
       // written where they are written
       PayPtrs pp;
       memset(&pp, 0, sizeof(pp));
-      pp.n = 1;
+      pp.n = n_pay;
       pp.positional = 1;
-      pp.src[0] = p == 0 ? pay_src[0] : carry_buf[(p - 1) & 1];
-      pp.out[0] = carry_buf[p & 1];
+      for (int c = 0; c < n_pay; ++c) {
+        pp.src[c] = p == 0 ? pay_src[c] : carry_buf[2 * c + ((p - 1) & 1)];
+        pp.out[c] = carry_buf[2 * c + (p & 1)];
+      }
       radix_one_pass<1024, 12, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carry_at) *carry_at = p & 1;
     } else if (last && n_pay > 0) {
-      for (int c0 = 0; c0 < n_pay; c0 += kMaxPay) {
+      constexpr int kPerLaunch = 1;  // columns fetched through the row ids per launch of the last pass
+      for (int c0 = 0; c0 < n_pay; c0 += kPerLaunch) {
         PayPtrs pp;
         memset(&pp, 0, sizeof(pp));
-        pp.n = n_pay - c0 < kMaxPay ? n_pay - c0 : kMaxPay;
+        pp.n = n_pay - c0 < kPerLaunch ? n_pay - c0 : kPerLaunch;
         for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
         // a replay for further columns reuses the offsets of the first launch
         radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, c0 > 0, pack, id_bits);
@@ -1363,9 +1386,9 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   TMP_REQUIRE(n_pay <= kMaxPay, TMP_EUNSUPPORTED, "ordering: at most %d payload column(s) per call", kMaxPay);
   // a payload column either travels with the rows through every partition pass (buffers planned
   // for it: all its reads and writes stream) or is fetched through the row ids at the very end
-  const bool carry = n_pay == 1 && b.carry[0] && b.carry[1];
+  bool carry = n_pay >= 1 && n_pay <= b.carry_cols;
   int carry_at = 0;
-  TMP_TRY(radix_passes(b, s.n, lay.key_shift(), lay.key_shift() + bg.bits, &part, st, carry ? 1 : 0,
+  TMP_TRY(radix_passes(b, s.n, lay.key_shift(), lay.key_shift() + bg.bits, &part, st, carry ? n_pay : 0,
                        carry ? pay_src : nullptr, nullptr, nullptr, &bgen, carry ? b.carry : nullptr, &carry_at));
   const int at = part.comp == b.comp[0] ? 0 : 1;
   PayPtrs pp;
@@ -1374,7 +1397,7 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
   if (carry) {
     pp.positional = 1;
-    pp.src[0] = b.carry[carry_at];
+    for (int c = 0; c < n_pay; ++c) pp.src[c] = b.carry[2 * c + carry_at];
   }
   const int64_t n_tiles = (s.n + TS_TILE - 1) / TS_TILE;
   TMP_LAUNCH(tile_bounds_kernel, dim3((unsigned)((n_tiles + 1 + 3) / 4)), dim3(kBlock), st, b.comp[at], s.n,
