@@ -206,6 +206,7 @@ struct GenArgs {
   const uint32_t *key_base;
   uint64_t inv;
   uint32_t last_key;  // n_keys - 1: key ids beyond the dictionary are read as the last key
+  int vec4;           // the columns are aligned for make_words4 (set where the words are laid out)
 };
 
 __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
@@ -231,6 +232,67 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   for (int m = 0; m < g.n_masks; ++m)
     if (!g.masks.p[m] || g.masks.p[m][i]) w |= 1ull << m;
   return w;
+}
+
+// Sort words of the four rows i .. i + 3 (i a multiple of 4, all four inside the table), with
+// 16-byte loads of the key and time columns and 4-byte loads of the NULL masks; the caller has
+// checked that those columns are aligned for it (gen_vector_ok).
+__device__ __forceinline__ void make_words4(const GenArgs &g, int64_t i, uint64_t w[4]) {
+  const Layout &lay = g.lay;
+  const longlong2 ta = *reinterpret_cast<const longlong2 *>(g.ts + i);
+  const longlong2 tb = *reinterpret_cast<const longlong2 *>(g.ts + i + 2);
+  const int64_t t[4] = {ta.x, ta.y, tb.x, tb.y};
+  int4 kv = make_int4(0, 0, 0, 0);
+  if (g.key) kv = *reinterpret_cast<const int4 *>(g.key + i);
+  const uint32_t kk[4] = {(uint32_t)kv.x, (uint32_t)kv.y, (uint32_t)kv.z, (uint32_t)kv.w};
+  uint64_t rel[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t p = lay.prim_div == 1 ? t[u] : floordiv_i64(t[u], lay.prim_div);
+    rel[u] = (uint64_t)(p - lay.prim_min);
+    if (lay.prim_gran != 1) rel[u] = (uint64_t)floordiv_i64((int64_t)rel[u], lay.prim_gran);
+    w[u] = rel[u] << lay.prim_shift();
+  }
+  if (g.key_nb) {
+    uint32_t nb[4], base[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t k = kk[u] < g.last_key ? kk[u] : g.last_key;
+      nb[u] = g.key_nb[k];
+      base[u] = g.key_base[k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint64_t q = __umul64hi(rel[u] * nb[u], g.inv);
+      if (q >= nb[u]) q = nb[u] - 1;
+      w[u] |= (uint64_t)(base[u] + (uint32_t)q) << lay.key_shift();
+    }
+  } else if (lay.key_bits) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] |= (uint64_t)kk[u] << lay.key_shift();
+  }
+  if (lay.seq_bits && g.seq) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool sv = !g.seq_valid || g.seq_valid[i + u];
+      if (sv) w[u] |= (uint64_t)(g.seq[i + u] - lay.seq_min + 1) << lay.seq_shift();
+    }
+  }
+  for (int m = 0; m < g.n_masks; ++m) {
+    uint32_t v = 0x01010101u;
+    if (g.masks.p[m]) v = *reinterpret_cast<const uint32_t *>(g.masks.p[m] + i);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if ((v >> (8 * u)) & 0xffu) w[u] |= 1ull << m;
+  }
+}
+
+// Whether make_words4 may be used on these columns (host side).
+static bool gen_vector_ok(const GenArgs &g) {
+  uintptr_t a16 = (uintptr_t)g.ts | (uintptr_t)g.key;
+  uintptr_t a4 = 0;
+  for (int m = 0; m < g.n_masks; ++m) a4 |= (uintptr_t)g.masks.p[m];
+  return (a16 & 15) == 0 && (a4 & 3) == 0;
 }
 
 __global__ __launch_bounds__(kBlock) void make_comp_kernel(int64_t n, GenArgs g, uint64_t *comp,
@@ -287,6 +349,30 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
   int64_t end = begin + (int64_t)tiles_per_block * RS_TILE;
   if (end > n) end = n;
   int wave = threadIdx.x >> 6;
+  if (GEN && gen.vec4) {
+    // four consecutive rows per thread, wide loads and stores (begin is a multiple of the tile)
+    for (int64_t i = begin + (int64_t)threadIdx.x * 4; i < end; i += (int64_t)RS_THREADS * 4) {
+      uint64_t w[4];
+      if (i + 4 <= end) {
+        make_words4(gen, i, w);
+        if (GEN == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = (w[u] << gen.id_bits) | (uint64_t)(i + u);
+        }
+        *reinterpret_cast<ulonglong2 *>(words + i) = make_ulonglong2(w[0], w[1]);
+        *reinterpret_cast<ulonglong2 *>(words + i + 2) = make_ulonglong2(w[2], w[3]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) atomicAdd(&hist[wave][(uint32_t)(w[u] >> shift) & mask], 1u);
+      } else {
+        for (int64_t r = i; r < end; ++r) {
+          uint64_t x = make_word(gen, r);
+          if (GEN == 2) x = (x << gen.id_bits) | (uint64_t)r;
+          words[r] = x;
+          atomicAdd(&hist[wave][(uint32_t)(x >> shift) & mask], 1u);
+        }
+      }
+    }
+  } else {
   // four rows per thread and round: all their loads are issued before the first store or counter
   // update, so a wave keeps four requests per column in flight instead of one
   constexpr int UN = 4;
@@ -313,6 +399,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
         atomicAdd(&hist[wave][(uint32_t)(w[u] >> shift) & mask], 1u);
       }
     }
+  }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
@@ -1352,6 +1439,7 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   gen.lay = lay;
   gen.n_masks = s.n_masks;
   for (int m = 0; m < TMP_MAX_MASKS; ++m) gen.masks.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
+  gen.vec4 = gen_vector_ok(gen) ? 1 : 0;
   const int lo_bit = sorted == 2 ? lay.key_shift() : lay.low_bits, hi_bit = lay.total_bits();
   if (sorted == 1 || lo_bit >= hi_bit) {  // no pass to run: the words in input order are the result
     int grid = grid_for(s.n, kBlock * 4, 8192);
