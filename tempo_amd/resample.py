@@ -161,27 +161,36 @@ def aggregate(tsdf, freq, func, metricCols=None, prefix=None, fill=None):
     res = pd.concat(pieces, axis=1) if nb else pd.DataFrame(
         {p.name: p for p in pieces}, columns=[p.name for p in pieces])
 
-    if fill:
-        res = _fill_grid(res, tsdf, dur_us)
+    if fill and nb:
+        res = _fill_grid(res, tsdf, dur_us, r["key"], r["start"], n_keys)
     return res
 
 
-def _fill_grid(res, tsdf, dur_us):
+def _fill_grid(res, tsdf, dur_us, bucket_key, bucket_start, n_keys):
     """fill=True (python/tempo/resample.py:102-115): per key a regular grid from the first to the
-    last bucket, left-joined with the aggregates, numeric NULLs replaced by 0."""
-    step = np.timedelta64(dur_us, "us")
-    parts = []
-    groups = res.groupby(tsdf.partitionCols, sort=False, dropna=False) if tsdf.partitionCols else [((), res)]
-    for keyvals, g in groups:
-        grid = pd.DataFrame({tsdf.ts_col: np.arange(g[tsdf.ts_col].min(), g[tsdf.ts_col].max() + step, step)})
-        grid[tsdf.ts_col] = grid[tsdf.ts_col].astype(g[tsdf.ts_col].dtype)
-        if tsdf.partitionCols:
-            keyvals = keyvals if isinstance(keyvals, tuple) else (keyvals,)
-            for c, v in zip(tsdf.partitionCols, keyvals):
-                grid[c] = v
-        parts.append(grid.merge(g, on=tsdf.partitionCols + [tsdf.ts_col], how="left"))
-    out = pd.concat(parts, ignore_index=True) if parts else res
+    last bucket, left-joined with the aggregates, numeric NULLs replaced by 0.
+
+    The grid is the device's: tmp_interpolate expands every bucket row of a key into the run of
+    grid points up to the key's next bucket and reports, per grid row, the bucket row it stems from
+    and whether it was generated.  bucket_key / bucket_start are the device columns tmp_resample
+    returned (row b of `res` is bucket b)."""
+    g = ops.interpolate(bucket_key, bucket_start, n_keys, dur_us, "zero", [], [])
+    src = g["src"].cpu().numpy()
+    generated = g["ts_interp"].cpu().numpy().astype(bool)
+    ts_col = tsdf.ts_col
+    out = res.iloc[src].reset_index(drop=True)
+    ts_dtype = res[ts_col].dtype
+    tz = getattr(ts_dtype, "tz", None)
+    grid_ts = g["ts"].cpu().numpy()
+    if tz is None:
+        out[ts_col] = pd.Series(grid_ts.astype("datetime64[us]").astype(res[ts_col].to_numpy().dtype))
+    else:
+        out[ts_col] = pd.Series(pd.to_datetime(grid_ts, unit="us", utc=True).tz_convert(tz))
     for c in out.columns:
-        if col.spark_dtype(out[c]) in ("bigint", "double", "int", "float") and c not in tsdf.partitionCols:
-            out[c] = out[c].fillna(0)
+        if c in tsdf.partitionCols or c == ts_col:
+            continue
+        if col.spark_dtype(res[c]) in ("bigint", "double", "int", "float"):
+            out[c] = out[c].where(~generated, 0).fillna(0).astype(res[c].dtype)
+        else:
+            out[c] = out[c].where(~generated, None)
     return out[list(res.columns)]

@@ -112,31 +112,63 @@ class TSDF:
             if kind != "i64":
                 seq = seq.to(torch.int64)
 
-        # encode every right column for the device gather; columns with NULLs get a mask slot
-        enc = {c: col.any_to_device(right_df[c]) for c in right_cols}
-        masks, mask_of = [], {}
-        if skipNulls:
-            for c in right_cols:
-                if enc[c][1] is not None:
-                    mask_of[c] = len(masks)
-                    masks.append(enc[c][1])
-        if len(masks) > 16:
-            raise NotImplementedError("asofJoin supports at most 16 right columns with NULLs per call")
-
-        row_idx, mask_idx, missing = ops.asof_join(
-            col.to_dev(key_l), col.to_dev(ts_l), col.to_dev(key_r), col.to_dev(ts_r), n_keys,
-            seq_r=seq, seq_r_valid=seq_valid, masks=masks, ts_is_seconds=secs,
-            ts_partition_val=tsPartitionVal, fraction=fraction)
-
-        out = {c: left_df[c].reset_index(drop=True) for c in part}
-        for c in left_cols:
-            out[lname[c]] = left_df[c].reset_index(drop=True).rename(lname[c])
+        # One fused device call delivers the joined right columns in (key, ts) order -- the order
+        # Spark's window leaves them in -- together with the left row every output row stems from;
+        # the left columns follow by that permutation on the host.  Every right column travels as
+        # an 8-byte device column (narrower encodings are widened and narrowed back on the way out);
+        # the right time index is the join's own time column.
+        enc, dev_cols, dev_masks = {}, [], []
         for c in right_cols:
-            values, valid, decode = enc[c]
-            idx = mask_idx[mask_of[c]] if c in mask_of else row_idx
-            g, gv = ops.gather(values, idx, valid)
-            out[rname[c]] = decode(g.cpu().numpy(), gv.cpu().numpy().astype(bool)).rename(rname[c])
+            if c == right_tsdf.ts_col:
+                enc[c] = None
+                dev_cols.append(col.to_dev(ts_r))
+                dev_masks.append(None)
+                continue
+            values, valid, decode = col.any_to_device(right_df[c])
+            enc[c] = (values.dtype, decode)
+            if values.dtype == torch.float32:
+                values = values.to(torch.float64)
+            elif values.dtype not in (torch.float64, torch.int64):
+                values = values.to(torch.int64)
+            dev_cols.append(values)
+            dev_masks.append(valid)
+        if len({m.data_ptr() for m in dev_masks if m is not None}) > 16:
+            raise NotImplementedError("asofJoin supports at most 16 right columns with NULLs per call")
+        j = ops.asof_join_table(col.to_dev(key_l), col.to_dev(ts_l), col.to_dev(key_r), col.to_dev(ts_r), n_keys,
+                                [], dev_cols, dev_masks, skip_nulls=bool(skipNulls), seq_r=seq, seq_r_valid=seq_valid,
+                                ts_is_seconds=secs, ts_partition_val=tsPartitionVal, fraction=fraction)
+        perm = j["perm"].cpu().numpy()
+        left_sorted = left_df.iloc[perm].reset_index(drop=True)
+        out = {c: left_sorted[c] for c in part}
+        for c in left_cols:
+            out[lname[c]] = left_sorted[c].rename(lname[c])
+        mask_of = {}
+        for k, c in enumerate(right_cols):
+            values, valid = j["right"][k]
+            v, ok = values.cpu().numpy(), valid.cpu().numpy().astype(bool)
+            if enc[c] is None:  # the right time index: microseconds (or the integral column itself)
+                ts_dtype = right_df[c].dtype
+                if secs:
+                    ser = pd.Series(pd.array(np.where(ok, v, 0), dtype="int64"), name=rname[c])
+                    ser = ser.astype(ts_dtype) if ok.all() else ser.astype(pd.Int64Dtype()).where(ok, pd.NA)
+                else:
+                    ser = pd.Series(v.astype("datetime64[us]").astype("datetime64[ns]"), name=rname[c])
+                    tz = getattr(ts_dtype, "tz", None)
+                    if tz is not None:
+                        ser = ser.dt.tz_localize("UTC").dt.tz_convert(tz)
+                    ser = ser.where(ok, pd.NaT)
+                out[rname[c]] = ser
+            else:
+                dtype, decode = enc[c]
+                if dtype == torch.float32:
+                    v = v.astype(np.float32)
+                elif dtype not in (torch.float64, torch.int64):
+                    v = v.astype(torch.empty(0, dtype=dtype).numpy().dtype)
+                out[rname[c]] = decode(v, ok).rename(rname[c])
+            if j["mask_of"][k] >= 0:
+                mask_of[c] = j["mask_of"][k]
         joined = pd.concat([out[k].rename(k) for k in out], axis=1)
+        missing = j["missing"]
 
         if tsPartitionVal is not None and (not suppress_null_warning or logger.isEnabledFor(logging.WARNING)):
             miss = missing.cpu().numpy()

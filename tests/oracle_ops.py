@@ -34,6 +34,43 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
     return _t(idx[0], torch.int32), _t(idx[1:].reshape(len(masks), nL), torch.int32), _t(missing, torch.int32)
 
 
+def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks, skip_nulls=True,
+                    seq_r=None, seq_r_valid=None, ts_is_seconds=False, ts_partition_val=None, fraction=0.5):
+    """The fused join's result from the oracle's match indices: rows in (key, ts) order (ties in
+    input order), left / right columns gathered on the host."""
+    nL, nR = ts_l.numel(), ts_r.numel()
+    kl = _np(key_l) if key_l is not None else np.zeros(nL, np.int32)
+    kr = _np(key_r) if key_r is not None else np.zeros(nR, np.int32)
+    masks, mask_of = [], []
+    for m in right_col_masks:
+        if m is None:
+            mask_of.append(-1)
+            continue
+        slot = next((k for k, mm in enumerate(masks) if mm is m), None)
+        if slot is None:
+            slot = len(masks)
+            masks.append(m)
+        mask_of.append(slot)
+    idx, missing = oracle.asof_join(kl, _np(ts_l), kr, _np(ts_r), seq_r=_np(seq_r), seq_r_valid=_np(seq_r_valid),
+                                    valid_r=[None] + [_np(m) for m in masks], skip_nulls=True,
+                                    ts_is_seconds=ts_is_seconds, ts_partition_val=ts_partition_val, fraction=fraction)
+    tl = _np(ts_l)
+    perm = np.lexsort((np.arange(nL), tl, kl))
+    right = []
+    for c, colv in enumerate(right_cols):
+        v = _np(colv)
+        slot = mask_of[c]
+        src = idx[1 + slot] if (skip_nulls and slot >= 0) else idx[0]
+        ok = src >= 0
+        if not skip_nulls and slot >= 0:
+            ok = ok & (_np(masks[slot])[np.maximum(src, 0)] != 0)
+        vals = np.where(ok, v[np.maximum(src, 0)], 0) if nR else np.zeros(nL, v.dtype)
+        right.append((_t(vals[perm].astype(v.dtype)), _t(ok[perm].astype(np.uint8))))
+    return dict(perm=_t(perm, torch.int32), key=_t(kl[perm]), ts=_t(tl[perm]),
+                left=[_t(_np(c)[perm]) for c in left_cols], right=right, missing=_t(missing, torch.int32),
+                mask_of=mask_of)
+
+
 def gather(src, idx, src_valid=None, want_valid=True):
     i = idx.to(torch.int64)
     ok = i >= 0
