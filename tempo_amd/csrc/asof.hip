@@ -26,6 +26,7 @@ struct AsofPlan {
   uint64_t *rrec;    // [n_right][stride] packed right payload records (2+ columns)
   uint64_t *rsort[kMaxPay];  // right payload columns in sorted order (when the ordering step carries them)
   int64_t *block_bounds;     // [merge blocks + 1]
+  uint16_t *cmask;           // [n_right] validity bits in sorted order, when they do not fit the sort words
 };
 
 // 8-byte words per packed payload record: a power of two up to 4 (so that a record never
@@ -62,7 +63,7 @@ template <bool REV>
 __global__ __launch_bounds__(kUnitBlock) void lastnn_reduce_kernel(const uint64_t *comp, int64_t n,
                                                                    int n_masks,
                                                                    int64_t rows_per_unit, int units,
-                                                                   int32_t *unit_agg) {
+                                                                   int32_t *unit_agg, const uint16_t *ext) {
   int unit = blockIdx.x * (kUnitBlock / 64) + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (unit >= units) return;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_reduce_kernel(const uint64_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t i = base + r * 64 + lane;
-      w[r] = i < end ? comp[REV ? n - 1 - i : i] : 0ull;
+      w[r] = i < end ? (ext ? (uint64_t)ext[REV ? n - 1 - i : i] : comp[REV ? n - 1 - i : i]) : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
                                                                  int n_masks,
                                                                  int64_t rows_per_unit, int units,
                                                                  const int32_t *unit_agg,
-                                                                 int32_t *lastnn) {
+                                                                 int32_t *lastnn, const uint16_t *ext) {
   int unit = blockIdx.x * (kUnitBlock / 64) + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (unit >= units) return;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t i = base + r * 64 + lane;
-      w[r] = i < end ? comp[REV ? n - 1 - i : i] : 0ull;
+      w[r] = i < end ? (ext ? (uint64_t)ext[REV ? n - 1 - i : i] : comp[REV ? n - 1 - i : i]) : 0ull;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -172,22 +173,22 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
 size_t last_valid_scratch_ints() { return (size_t)TMP_MAX_MASKS * kUnits; }
 
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
-                    bool reverse, hipStream_t st) {
+                    bool reverse, hipStream_t st, const uint16_t *ext) {
   if (n <= 0 || n_masks <= 0) return TMP_OK;
   ScanGeom g = scan_geom(n);
   int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
   if (reverse) {
     TMP_LAUNCH(lastnn_reduce_kernel<true>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg);
+               g.rows_per_unit, g.units, unit_agg, ext);
     TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
     TMP_LAUNCH(lastnn_scan_kernel<true>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg, out);
+               g.rows_per_unit, g.units, unit_agg, out, ext);
   } else {
     TMP_LAUNCH(lastnn_reduce_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg);
+               g.rows_per_unit, g.units, unit_agg, ext);
     TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
     TMP_LAUNCH(lastnn_scan_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg, out);
+               g.rows_per_unit, g.units, unit_agg, out, ext);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
     SkewParams sp, int32_t *out_idx, int32_t *out_missing, int sorted_output, int32_t *out_perm,
-    int32_t *out_key, int64_t *out_ts, JoinCols jc, const int64_t *block_bounds) {
+    int32_t *out_key, int64_t *out_ts, JoinCols jc, const int64_t *block_bounds, const uint16_t *cmask) {
   __shared__ uint64_t rw[kMergeRight];
   const int low = lay.low_bits;
   int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
@@ -382,9 +383,11 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
           }
         }
       }
+      // validity bits of the matched row: the low bits of its word, or the separate array
+      const uint64_t mrow = cmask ? (jrow >= 0 ? (uint64_t)cmask[jrow] : 0ull) : wr_row;
       for (int c = 0; c < jc.n; ++c) {  // columns that follow the row rule
         if (jc.rule[c] >= 0) continue;
-        bool okv = jrow >= 0 && (jc.vmask[c] < 0 || ((wr_row >> jc.vmask[c]) & 1ull));
+        bool okv = jrow >= 0 && (jc.vmask[c] < 0 || ((mrow >> jc.vmask[c]) & 1ull));
         const int sl = jc.slot[c];
         uint64_t v = sl < 0 ? (uint64_t)lay.prim_of(wr_row)
                             : (sl == 0 ? q0 : sl == 1 ? q1 : sl == 2 ? q2 : sl == 3 ? q3 : (rr ? rr[sl] : 0ull));
@@ -417,9 +420,10 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       if (rec) rec[1 + m] = jm < 0 ? -1 : (jm == jrow && row_src >= 0 ? row_src : (int32_t)perm_r[jm]);
       miss_mask |= (uint32_t)(jm < 0) << m;
       const uint64_t *rm = nullptr;
+      const uint64_t mm = cmask ? (jm >= 0 ? (uint64_t)cmask[jm] : 0ull) : wm;
       for (int c = 0; c < jc.n; ++c) {
         if (jc.rule[c] != m) continue;
-        bool okv = jm >= 0 && (jc.vmask[c] < 0 || ((wm >> jc.vmask[c]) & 1ull));
+        bool okv = jm >= 0 && (jc.vmask[c] < 0 || ((mm >> jc.vmask[c]) & 1ull));
         uint64_t v = 0;
         if (okv) {
           const int sl = jc.slot[c];
@@ -473,6 +477,7 @@ static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
   size_t nm = (size_t)(a->n_masks > 0 ? a->n_masks : 1);
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());
+  p->cmask = ws.take<uint16_t>(a->n_masks > 0 ? (size_t)(a->n_right > 0 ? a->n_right : 1) : 1);
   p->block_bounds = ws.take<int64_t>((size_t)(a->n_left / (kBlock * kMergeRows) + 3));
   const int nlc = a->sorted_output ? a->n_left_cols : 0;
   p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
@@ -557,6 +562,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   rs.seq = a->seq_right; rs.seq_valid = a->seq_right_valid;
   rs.n_masks = a->n_masks;
   ls.coarse_ok = rs.coarse_ok = 1;
+  rs.ext_masks_ok = 1;
   for (int m = 0; m < a->n_masks; ++m) rs.masks[m] = a->masks[m];
 
   // ranges of both sides, one host read each, then one shared bit layout
@@ -648,7 +654,12 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     TMP_LAUNCH(pack_rows_kernel, dim3(grid_for(a->n_right * (jc.rstride / 2), kBlock, 8192)), dim3(kBlock), st, pr, a->n_right, p.rrec);
   }
 
-  TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, st));
+  const uint16_t *cmask = nullptr;
+  if (lay.ext_masks && a->n_right > 0) {  // the validity bits did not fit the sort words
+    TMP_TRY(order_gather_masks(rs, ro, p.cmask, st));
+    cmask = p.cmask;
+  }
+  TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, st, cmask));
   SkewParams sp;
   sp.enabled = a->skew != 0;
   sp.v_is_int = a->v_is_int;
@@ -660,7 +671,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
              a->n_right, lay.low_bits, kBlock * kMergeRows, (int64_t)grid, p.block_bounds);
   TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
                      ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds);
+                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

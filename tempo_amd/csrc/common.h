@@ -79,6 +79,14 @@ struct Layout {
   int64_t seq_min;
   int64_t prim_div;
   int64_t prim_gran;
+  // Wide tables.  seq_wide: the sequence values do not fit next to key and time; the word then
+  // keeps one bit for them (0 = NULL, which sorts first, 1 = a value) and the ordering step sorts
+  // by the values themselves in passes of their own (seq_full_bits wide) before the word's.
+  // ext_masks > 0: the validity bits of that many payload columns do not fit either; low_bits is
+  // 0 and they are handed to the consumers as a separate array in sorted order.
+  int seq_wide;
+  int seq_full_bits;
+  int ext_masks;
   __host__ __device__ int seq_shift() const { return low_bits; }
   __host__ __device__ int prim_shift() const { return low_bits + seq_bits; }
   __host__ __device__ int key_shift() const { return low_bits + seq_bits + prim_bits; }
@@ -117,6 +125,7 @@ struct OrderSpec {
   int n_masks;
   const uint8_t *masks[TMP_MAX_MASKS];
   int coarse_ok;  // the caller reads times only through Layout::prim_of: prim_gran may be used
+  int ext_masks_ok;  // the caller can take the validity bits as a separate array (order_gather_masks)
 };
 
 struct OrderBuffers {
@@ -175,12 +184,15 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
 // One-call form for ops that order a single table.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);
+// Layouts with ext_masks: out[p] = validity bits (bit m = mask m) of the row at sorted position p.
+int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out, hipStream_t st);
 
 // Per mask bit m < n_masks of the sort words: out[m*n + j] = last position <= j whose bit is set
 // (reverse: first position >= j), or -1.  unit_agg: last_valid_scratch_ints() int32 of scratch.
 size_t last_valid_scratch_ints();
+// ext: the mask bits as a separate array (Layout::ext_masks) instead of the words' low bits.
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
-                    bool reverse, hipStream_t st);
+                    bool reverse, hipStream_t st, const uint16_t *ext = nullptr);
 // Exclusive scan of `total` uint32 counters in place.
 int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st);
 

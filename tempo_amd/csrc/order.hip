@@ -227,7 +227,7 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   }
   if (lay.seq_bits && g.seq) {
     bool sv = !g.seq_valid || g.seq_valid[i];
-    if (sv) w |= (uint64_t)(g.seq[i] - lay.seq_min + 1) << lay.seq_shift();
+    if (sv) w |= (lay.seq_wide ? 1ull : (uint64_t)(g.seq[i] - lay.seq_min + 1)) << lay.seq_shift();
   }
   for (int m = 0; m < g.n_masks; ++m)
     if (!g.masks.p[m] || g.masks.p[m][i]) w |= 1ull << m;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void make_words4(const GenArgs &g, int64_t i, uint64_
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const bool sv = !g.seq_valid || g.seq_valid[i + u];
-      if (sv) w[u] |= (uint64_t)(g.seq[i + u] - lay.seq_min + 1) << lay.seq_shift();
+      if (sv) w[u] |= (lay.seq_wide ? 1ull : (uint64_t)(g.seq[i + u] - lay.seq_min + 1)) << lay.seq_shift();
     }
   }
   for (int m = 0; m < g.n_masks; ++m) {
@@ -1185,6 +1185,38 @@ __global__ void copy_pairs_if_kernel(const uint64_t *win, const uint32_t *idin, 
   }
 }
 
+// Wide sequence columns: words that hold just the sequence field (0 = NULL, else value - min + 1)
+// with identity row ids, and -- after the passes over those -- the real sort words taken in the
+// order the row ids then stand in.
+__global__ __launch_bounds__(kBlock) void seq_words_kernel(int64_t n, const int64_t *seq, const uint8_t *seq_valid,
+                                                           int64_t seq_min, uint64_t *words, uint32_t *idx) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool sv = !seq_valid || seq_valid[i];
+    words[i] = sv ? (uint64_t)(seq[i] - seq_min) + 1ull : 0ull;
+    idx[i] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void make_comp_by_id_kernel(int64_t n, GenArgs g, const uint32_t *idx,
+                                                                 uint64_t *comp) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
+    comp[p] = make_word(g, (int64_t)idx[p]);
+}
+
+__global__ __launch_bounds__(kBlock) void gather_masks_kernel(int64_t n, const uint32_t *perm, int n_masks,
+                                                              MaskPtrs masks, uint16_t *out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const uint32_t i = perm[p];
+    uint32_t bits = 0;
+    for (int m = 0; m < n_masks; ++m)
+      if (!masks.p[m] || masks.p[m][i]) bits |= 1u << m;
+    out[p] = (uint16_t)bits;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
@@ -1259,6 +1291,17 @@ int order_make_layout(const OrderSpec &s, const RangeInfo &r, int low_bits, Layo
     }
   }
   l.key_bits = s.key ? bits_for((uint64_t)(s.n_keys > 1 ? s.n_keys - 1 : 0)) : 0;
+  l.seq_wide = 0;
+  l.seq_full_bits = l.seq_bits;
+  l.ext_masks = 0;
+  if (l.total_bits() > 64 && l.seq_bits > 1) {  // sequence values sorted in passes of their own
+    l.seq_wide = 1;
+    l.seq_bits = 1;
+  }
+  if (l.total_bits() > 64 && l.low_bits > 0 && s.ext_masks_ok) {  // validity bits beside the words
+    l.ext_masks = l.low_bits;
+    l.low_bits = 0;
+  }
   TMP_REQUIRE(l.total_bits() <= 64, TMP_EUNSUPPORTED,
               "sort word needs %d bits (key %d + time %d + sequence %d + masks %d) > 64",
               l.total_bits(), l.key_bits, l.prim_bits, l.seq_bits, l.low_bits);
@@ -1340,8 +1383,8 @@ static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbit
 static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
                         hipStream_t st, int n_pay, const uint64_t *const *pay_src,
                         uint64_t *const *pay_out, bool *carried, const GenArgs *gen,
-                        uint64_t *const *carry_buf = nullptr, int *carry_at = nullptr) {
-  int cur = 0;
+                        uint64_t *const *carry_buf = nullptr, int *carry_at = nullptr, int start_cur = 0) {
+  int cur = start_cur;
   if (carried) *carried = false;
   PayPtrs none;
   memset(&none, 0, sizeof(none));
@@ -1416,7 +1459,7 @@ static int passes_for(int bits) {
 // The bucketed ordering serves a full sort of a large table whose buffers were planned for it,
 // when the bucket field fits the word and the passes saved outweigh the tile kernel.
 static bool bucketed_wanted(const OrderSpec &s, const Layout &lay, int sorted, const OrderBuffers &b, BucketGeom *g) {
-  if (sorted != 0 || !b.key_nb || !b.fallback) return false;
+  if (sorted != 0 || !b.key_nb || !b.fallback || lay.seq_wide) return false;
   if (getenv("TEMPO_PLAIN_SORT")) return false;  // diagnostic switch: always the plain LSD passes
   const int64_t nk = plan_keys(s.key, s.n_keys);
   *g = bucket_geometry(s.n, nk);
@@ -1437,7 +1480,7 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   memset(&gen, 0, sizeof(gen));
   gen.key = s.key; gen.ts = s.ts; gen.seq = s.seq; gen.seq_valid = s.seq_valid;
   gen.lay = lay;
-  gen.n_masks = s.n_masks;
+  gen.n_masks = lay.ext_masks ? 0 : s.n_masks;  // validity bits beside the words: not in them
   for (int m = 0; m < TMP_MAX_MASKS; ++m) gen.masks.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
   gen.vec4 = gen_vector_ok(gen) ? 1 : 0;
   const int lo_bit = sorted == 2 ? lay.key_shift() : lay.low_bits, hi_bit = lay.total_bits();
@@ -1446,6 +1489,17 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, gen, b.comp[0], b.idx[0]);
     TMP_CHECK_HIP(hipGetLastError());
     return TMP_OK;
+  }
+  if (lay.seq_wide && s.seq && sorted == 0) {
+    // the sequence values first (stable passes over words that hold nothing else), then the sort
+    // words -- laid out in the order those passes left, through the row ids -- over their own bits
+    const int grid = grid_for(s.n, kBlock * 4, 8192);
+    TMP_LAUNCH(seq_words_kernel, dim3(grid), dim3(kBlock), st, s.n, s.seq, s.seq_valid, lay.seq_min, b.comp[0], b.idx[0]);
+    OrderResult by_seq;
+    TMP_TRY(radix_passes(b, s.n, 0, lay.seq_full_bits, &by_seq, st, 0, nullptr, nullptr, nullptr, nullptr));
+    const int at = by_seq.comp == b.comp[0] ? 0 : 1;
+    TMP_LAUNCH(make_comp_by_id_kernel, dim3(grid), dim3(kBlock), st, s.n, gen, b.idx[at], b.comp[at]);
+    return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr, nullptr, nullptr, at);
   }
   BucketGeom bg;
   if (!bucketed_wanted(s, lay, sorted, b, &bg))
@@ -1511,6 +1565,16 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   res->comp = b.comp[at ^ 1];
   res->perm = b.idx[at ^ 1];
   if (carried) *carried = n_pay > 0;
+  return TMP_OK;
+}
+
+int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out, hipStream_t st) {
+  if (s.n <= 0) return TMP_OK;
+  MaskPtrs mp;
+  for (int m = 0; m < TMP_MAX_MASKS; ++m) mp.p[m] = m < s.n_masks ? s.masks[m] : nullptr;
+  TMP_LAUNCH(gather_masks_kernel, dim3(grid_for(s.n, kBlock * 4, 8192)), dim3(kBlock), st, s.n, res.perm, s.n_masks, mp,
+             out);
+  TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }
 

@@ -54,8 +54,55 @@ def sort_order(key, ts, n_keys, floor_seconds=False, seq=None, seq_valid=None):
     return perm
 
 
+def _too_wide(err):
+    """The library's refusal of a table whose (key, time[, sequence flag]) does not fit one 64-bit
+    sort word even with the sequence values and validity bits moved out of it."""
+    return "sort word needs" in str(err)
+
+
+def _key_halves(key_l, key_r, n_keys):
+    """Row selections of the two halves of the key dictionary, for joining a table whose sort word
+    is too wide half by half (series are independent per key, and key order is row order)."""
+    mid = n_keys // 2
+    for lo, hi in ((0, mid), (mid, n_keys)):
+        sel_l = torch.nonzero((key_l >= lo) & (key_l < hi)).squeeze(1)
+        sel_r = torch.nonzero((key_r >= lo) & (key_r < hi)).squeeze(1)
+        yield lo, hi, sel_l, sel_r
+
+
+def _take(t, sel):
+    return None if t is None else t[sel].contiguous()
+
+
 def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, masks=(),
               ts_is_seconds=False, ts_partition_val=None, fraction=0.5, sorted_output=False):
+    """AS-OF match; a table too wide for one sort word is joined one half of the key dictionary at
+    a time (left row order only)."""
+    try:
+        return _asof_join_once(key_l, ts_l, key_r, ts_r, n_keys, seq_r, seq_r_valid, masks, ts_is_seconds,
+                               ts_partition_val, fraction, sorted_output)
+    except NotImplementedError as err:
+        if not _too_wide(err) or key_l is None or n_keys < 2 or sorted_output:
+            raise
+    masks = list(masks)
+    nL = ts_l.numel()
+    idx = torch.full((nL, 1 + len(masks)), -1, dtype=torch.int32, device=ts_l.device)
+    missing = torch.zeros(1 + len(masks), dtype=torch.int32, device=ts_l.device)
+    for lo, hi, sel_l, sel_r in _key_halves(key_l, key_r, n_keys):
+        if sel_l.numel() == 0:
+            continue
+        row, midx, miss = asof_join(_take(key_l, sel_l) - lo, _take(ts_l, sel_l), _take(key_r, sel_r) - lo,
+                                    _take(ts_r, sel_r), hi - lo, _take(seq_r, sel_r), _take(seq_r_valid, sel_r),
+                                    [_take(m, sel_r) for m in masks], ts_is_seconds, ts_partition_val, fraction)
+        sub = torch.cat([row.unsqueeze(1), midx.t()], dim=1).long()
+        back = torch.where(sub >= 0, sel_r[sub.clamp(min=0)] if sel_r.numel() else sub, sub)
+        idx[sel_l] = back.to(torch.int32)
+        missing |= miss
+    return idx[:, 0], idx[:, 1:].t(), missing
+
+
+def _asof_join_once(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, masks=(),
+                    ts_is_seconds=False, ts_partition_val=None, fraction=0.5, sorted_output=False):
     """AS-OF match (python/tempo/tsdf.py:463-560).
 
     Returns (row_idx[nL], mask_idx[n_masks, nL], missing[1 + n_masks]) as int32 device tensors:
@@ -110,6 +157,39 @@ def asof_join(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=None, ma
 def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
                     skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
                     ts_partition_val=None, fraction=0.5):
+    """Fused AS-OF join; a table too wide for one sort word is joined one half of the key
+    dictionary at a time and the halves are concatenated (key order is row order)."""
+    try:
+        return _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
+                                     skip_nulls, seq_r, seq_r_valid, ts_is_seconds, ts_partition_val, fraction)
+    except NotImplementedError as err:
+        if not _too_wide(err) or key_l is None or n_keys < 2:
+            raise
+    parts = []
+    for lo, hi, sel_l, sel_r in _key_halves(key_l, key_r, n_keys):
+        taken = {}  # one selection per distinct mask, so that shared masks stay shared
+        sub_masks = []
+        for m in right_col_masks:
+            if m is not None and m.data_ptr() not in taken:
+                taken[m.data_ptr()] = _take(m, sel_r)
+            sub_masks.append(None if m is None else taken[m.data_ptr()])
+        j = asof_join_table(_take(key_l, sel_l) - lo, _take(ts_l, sel_l), _take(key_r, sel_r) - lo, _take(ts_r, sel_r),
+                            hi - lo, [_take(c, sel_l) for c in left_cols], [_take(c, sel_r) for c in right_cols],
+                            sub_masks, skip_nulls, _take(seq_r, sel_r), _take(seq_r_valid, sel_r), ts_is_seconds,
+                            ts_partition_val, fraction)
+        j["perm"] = sel_l[j["perm"].long()].to(torch.int32)
+        j["key"] = j["key"] + lo
+        parts.append(j)
+    a, b = parts
+    return dict(perm=torch.cat([a["perm"], b["perm"]]), key=torch.cat([a["key"], b["key"]]),
+                ts=torch.cat([a["ts"], b["ts"]]), left=[torch.cat(p) for p in zip(a["left"], b["left"])],
+                right=[(torch.cat([x[0], y[0]]), torch.cat([x[1], y[1]])) for x, y in zip(a["right"], b["right"])],
+                missing=a["missing"] | b["missing"], mask_of=a["mask_of"])
+
+
+def _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
+                          skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
+                          ts_partition_val=None, fraction=0.5):
     """Fused AS-OF join: the joined table itself, in (key, ts) order, written with streaming
     accesses only (the payload columns ride along with the last radix pass of their table).
 

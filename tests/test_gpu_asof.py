@@ -236,3 +236,55 @@ def test_asof_timestamp_granularity(orc, ops, step_l, step_r):
     masks = [(rng.random(nR) >= 0.2).astype(np.uint8)]
     _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, None, None, masks), nk)
     _run_both(orc, ops, (key_l, ts_l, key_r, ts_r, None, None, masks), nk, ts_partition_val=30, fraction=0.3)
+
+
+YEAR_US = 366 * 86_400_000_000
+
+
+def _wide_tables(rng, nL, nR, nk, n_masks, seq_span):
+    key_l = rng.integers(0, nk, nL).astype(np.int32)
+    key_r = rng.integers(0, nk, nR).astype(np.int32)
+    # few distinct times per key, so that equal (key, ts) pairs -- where the sequence decides -- occur
+    ts_l = BASE + rng.integers(0, 2000, nL) * (YEAR_US // 2000) + rng.integers(0, 3, nL)
+    ts_r = BASE + rng.integers(0, 2000, nR) * (YEAR_US // 2000) + rng.integers(0, 3, nR)
+    ts_l[0], ts_r[0] = BASE, BASE + YEAR_US          # the whole year, to the microsecond: 45 bits
+    masks = [(rng.random(nR) >= 0.3).astype(np.uint8) for _ in range(n_masks)]
+    seq = seq_valid = None
+    if seq_span:
+        seq = rng.integers(-seq_span, seq_span, nR)
+        seq_valid = (rng.random(nR) >= 0.15).astype(np.uint8)
+    return key_l, ts_l, key_r, ts_r, seq, seq_valid, masks
+
+
+@pytest.mark.parametrize("nk,n_masks,seq_span,what", [
+    (900, 2, 2**30, "sequence values sorted in passes of their own"),          # 10 + 45 + 32 + 2 bits
+    (12_000, 8, 0, "validity bits beside the sort words"),                     # 14 + 45 + 8 bits
+    (3_000, 9, 2**20, "both"),                                                 # 12 + 45 + 22 + 9 bits
+    (1_000_000, 8, 2**12, "key dictionary joined in halves as well"),          # 20 + 45 alone exceed a word
+])
+def test_asof_tables_wider_than_one_sort_word(orc, ops, nk, n_masks, seq_span, what):
+    """(key, time, sequence, validity bits) beyond 64 bits: the reference joins such tables
+    (python/tempo/tsdf.py:117-121 has no width limit), so must the device path -- record mode and
+    fused table mode, with and without skipNulls."""
+    rng = np.random.default_rng(nk)
+    nL, nR = 60_000, 80_000
+    data = _wide_tables(rng, nL, nR, nk, n_masks, seq_span)
+    _run_both(orc, ops, data, nk)
+    key_l, ts_l, key_r, ts_r, seq, seq_valid, masks = data
+    vals = [rng.normal(0, 1, nR) for _ in masks]
+    for skip_nulls in (True, False):
+        out = ops.asof_join_table(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nk, [],
+                                  [_dev(ts_r)] + [_dev(v) for v in vals], [None] + [_dev(m) for m in masks],
+                                  skip_nulls=skip_nulls, seq_r=_dev(seq), seq_r_valid=_dev(seq_valid))
+        idx, omiss = orc.asof_join(key_l, ts_l, key_r, ts_r, seq_r=seq, seq_r_valid=seq_valid,
+                                   valid_r=[None] + masks, skip_nulls=skip_nulls)
+        p = out["perm"].cpu().numpy().astype(np.int64)
+        assert np.array_equal(p, np.lexsort((np.arange(nL), ts_l, key_l)))
+        for c, src in enumerate([ts_r] + vals):
+            j = (idx[c] if skip_nulls else idx[0])[p]
+            ok = j >= 0
+            if c > 0 and not skip_nulls:
+                ok = ok & (masks[c - 1][np.clip(j, 0, None)] == 1)
+            got, valid = out["right"][c]
+            assert np.array_equal(valid.cpu().numpy().astype(bool), ok), (what, c)
+            assert np.array_equal(got.cpu().numpy(), np.where(ok, src[np.clip(j, 0, None)], 0)), (what, c)
