@@ -136,7 +136,7 @@ struct EmaPlan {
 };
 
 static void ema_plan(const tmp_ema_args *a, Workspace &ws, EmaPlan *p) {
-  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys));
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys), 1);  // the metric travels with the rows
   p->xs = ws.take<double>((size_t)(a->n > 0 ? a->n : 1));
   p->w = ws.take<double>(TMP_MAX_TAPS);
 }

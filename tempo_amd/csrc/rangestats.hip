@@ -23,12 +23,21 @@ constexpr int RK_ROWS = 1024;
 constexpr int RK_CAP = 2560;
 constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
-constexpr int RK_SB = 8;                 // slots per sub-block
-constexpr int RK_NSB = RK_CAP / RK_SB;  // 320
+#ifndef TEMPO_RK_WPS
+#define TEMPO_RK_WPS 8
+#endif
+constexpr int RK_WAVES_PER_SIMD = TEMPO_RK_WPS;  // 8 = two 1024-thread blocks per CU (at most 64 VGPRs)
+#ifndef TEMPO_RK_SB
+#define TEMPO_RK_SB 8
+#endif
+constexpr int RK_SB = TEMPO_RK_SB;      // slots per sub-block (4 or 8)
+constexpr int RK_NSB = RK_CAP / RK_SB;  // 640
 constexpr int RK_GRP = 16;              // sub-blocks per group (one DPP row of lanes)
-constexpr int RK_NGRP = RK_NSB / RK_GRP;  // 20
-constexpr int RK_GLEVELS = 5;           // sparse table over the groups: spans up to 16 of them
-static_assert(RK_NSB % 64 == 0 && RK_NGRP <= 32, "group scans are laid out for whole waves");
+constexpr int RK_NGRP = RK_NSB / RK_GRP;  // 40
+constexpr int RK_GLEVELS = 6;           // sparse table over the groups: spans up to 32 of them
+static_assert(RK_SB == 4 || RK_SB == 8, "a sub-block is one or two 16-byte LDS reads of sort words");
+static_assert(RK_NSB % 64 == 0 && RK_NGRP <= 64 && (1 << RK_GLEVELS) > RK_NGRP && RK_NSB <= RK_THREADS,
+              "group scans are laid out for whole waves");
 
 // ---- DPP moves inside a 16-lane row (used by the min / max scans over groups of sub-blocks)
 template <int CTRL>
@@ -114,13 +123,13 @@ struct RsShared {
   // up to it and from it on, and a small sparse table over the group extremes
   T mn0[RK_NSB], mx0[RK_NSB];
   T mn_pre[RK_NSB], mn_suf[RK_NSB], mx_pre[RK_NSB], mx_suf[RK_NSB];
-  T gmn[RK_GLEVELS][32], gmx[RK_GLEVELS][32];
+  T gmn[RK_GLEVELS][64], gmx[RK_GLEVELS][64];
   int pivot_at;
   int nonfinite;  // some staged value is NaN or +-inf
 };
 
 template <typename T>
-__global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t *comp,
+__global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_kernel(const uint64_t *comp,
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
                                                                  uint64_t w, RsOut<T> o,
@@ -189,9 +198,12 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
     uint32_t sc = 0;
     uint64_t si = 0;
     T vmn = MinMax<T>::min_identity(), vmx = MinMax<T>::max_identity();
-    const uint4 c0 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB]);
-    const uint4 c1 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB + 4]);
-    const uint32_t cs[RK_SB] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    uint32_t cs[RK_SB];
+#pragma unroll
+    for (int q4 = 0; q4 < RK_SB / 4; ++q4) {
+      const uint4 c4 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB + 4 * q4]);
+      cs[4 * q4] = c4.x; cs[4 * q4 + 1] = c4.y; cs[4 * q4 + 2] = c4.z; cs[4 * q4 + 3] = c4.w;
+    }
 #pragma unroll
     for (int j = 0; j < RK_SB; ++j) {
       const T v = s.x[b * RK_SB + j];
@@ -261,22 +273,26 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
       s.bs[0] = 0.0; s.bq[0] = 0.0; s.bc[0] = 0u;
       if (kInt) s.bi[0] = 0ull;
     }
-  } else if (wave <= 2 * (RK_NSB / 64)) {
-    // waves 1..5: group scans of the minima, waves 6..10: of the maxima; lane = sub-block
-    const bool is_min = wave <= RK_NSB / 64;
-    const int b = ((wave - 1) % (RK_NSB / 64)) * 64 + lane;
-    if (is_min) {
-      const T v = s.mn0[b];
-      const T pre = group_scan<T, true, true>(v);
-      s.mn_pre[b] = pre;
-      s.mn_suf[b] = group_scan<T, true, false>(v);
-      if ((lane & 15) == 15) s.gmn[0][b / RK_GRP] = pre;
-    } else {
-      const T v = s.mx0[b];
-      const T pre = group_scan<T, false, true>(v);
-      s.mx_pre[b] = pre;
-      s.mx_suf[b] = group_scan<T, false, false>(v);
-      if ((lane & 15) == 15) s.gmx[0][b / RK_GRP] = pre;
+  } else {
+    // waves 1..15 share the group scans: chunk c < RK_NSB / 64 scans 64 minima, the others 64
+    // maxima; lane = sub-block
+    constexpr int kChunks = RK_NSB / 64;
+    for (int c = wave - 1; c < 2 * kChunks; c += RK_THREADS / 64 - 1) {
+      const bool is_min = c < kChunks;
+      const int b = (c % kChunks) * 64 + lane;
+      if (is_min) {
+        const T v = s.mn0[b];
+        const T pre = group_scan<T, true, true>(v);
+        s.mn_pre[b] = pre;
+        s.mn_suf[b] = group_scan<T, true, false>(v);
+        if ((lane & 15) == 15) s.gmn[0][b / RK_GRP] = pre;
+      } else {
+        const T v = s.mx0[b];
+        const T pre = group_scan<T, false, true>(v);
+        s.mx_pre[b] = pre;
+        s.mx_suf[b] = group_scan<T, false, false>(v);
+        if ((lane & 15) == 15) s.gmx[0][b / RK_GRP] = pre;
+      }
     }
   }
   __syncthreads();
@@ -287,10 +303,8 @@ __global__ __launch_bounds__(RK_THREADS) void range_stats_kernel(const uint64_t 
     for (int lv = 1; lv < RK_GLEVELS; ++lv) {
       T t = __shfl_down(v, 1 << (lv - 1), 64);
       v = wave == 0 ? MinMax<T>::mn(v, t) : MinMax<T>::mx(v, t);
-      if (lane < 32) {
-        if (wave == 0) s.gmn[lv][lane] = v;
-        else s.gmx[lv][lane] = v;
-      }
+      if (wave == 0) s.gmn[lv][lane] = v;
+      else s.gmx[lv][lane] = v;
     }
   }
   __syncthreads();
@@ -455,7 +469,7 @@ struct RsPlan {
 };
 
 static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p, bool with_wide) {
-  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys));
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys), 1);  // the metric travels with the rows
   p->xs = ws.take<uint64_t>((size_t)(a->n > 0 ? a->n : 1));
   p->deferred = ws.take<int32_t>(1);
   if (with_wide) rs_wide_plan(a->n, a->x_is_i64 != 0, ws, &p->wide);
