@@ -111,7 +111,7 @@ def gen_ticks(dev, n, n_keys, seed, key_offset=0):
 # algorithmic bytes one launch of a kernel moves, per row it processes (every input read once,
 # every output written once)
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r01_bench1b_pmc_traffic.json")
+                                "r02_bench1b_pmc_traffic.json")
 
 COPY_CEILING_FILE = os.path.join(os.path.dirname(PMC_TRAFFIC_FILE), "r01_copy_ceiling.json")
 
@@ -133,10 +133,15 @@ KERNEL_BYTES_PER_ROW = {
     "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out
     "radix_scatter_kernel+payload": 40.0,  # pair 12 + one 8 B payload column, in and out
     "pack_rows_kernel": 56.0,         # 3 x 8 B columns in, one 32 B record out
-    # per left row: word 8 + row id 4 + left payload 8 in; right word 8 + 2 x last-non-null 4 +
-    # row id 4 + one 32 B payload record in (the two sides have equal row counts);
-    # row id 4 + key 4 + ts 8 + left payload 8 + 3 x (value 8 + flag 1) out
-    "asof_merge_kernel": 123.0,
+    # per left row: word 8 + row id 4 in; right word 8 + 2 x last-non-null 4 + row id 4 + one 16 B
+    # payload record in (the two sides have equal row counts); row id 4 + key 4 + ts 8 +
+    # 3 x (value 8 + flag 1) out (the left payload column arrives in order from the tile sort)
+    "asof_merge_kernel": 107.0,
+    # bucketed ordering: word 8 + row id 4 in and out (+ 8 in and out for the travelling payload column)
+    "tile_sort_kernel": 24.0,
+    "radix_scatter_kernel+carried": 40.0,
+    "tile_bounds_kernel": 8.0,
+    "key_sample_kernel": 0.25,
     "lastnn_scan_kernel<false>": 16.0,       # word 8 in, 2 x 4 B out
     "lastnn_reduce_kernel<false>": 8.0,
     "range_scan_kernel": 12.0,        # key 4 + ts 8 in

@@ -24,9 +24,9 @@ def short(name):
     base, args = m.group(1), (m.group(3) or "")
     if base == "radix_scatter_kernel":
         npay = args.split(",")[2].strip()
-        return base + ("+payload" if npay != "0" else "")
+        return base + ("+carried" if npay.startswith("-") else "+payload" if npay != "0" else "")
     if base == "radix_hist_kernel":
-        return base + ("+words" if args.split(",")[-1].strip() in ("true", "1") else "")
+        return base + ("+words" if args.split(",")[-1].strip() in ("true", "1", "2") else "")
     if base == "range_stats_kernel":
         return "range_stats_kernel<T>"
     if base == "gather_kernel":
