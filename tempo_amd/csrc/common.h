@@ -112,7 +112,15 @@ struct RangeInfo {
   int32_t time_unsorted;  // rows are not even in (primary, seq) order, keys ignored
   int32_t not_thousands;  // some primary value is not a multiple of 1000
   int32_t not_millions;   // ... of 1000000
+  // rows at which (primary, seq) steps back: a table that is a handful of time-ordered runs laid
+  // end to end (what a rank holds after the key shuffle) has few of them.  n_desc counts them while
+  // it is <= kMaxDesc; desc_pos holds the first kMaxDesc positions found, in no particular order.
+  int32_t n_desc;
+  int32_t pad_;
+  int64_t desc_pos[15];
 };
+constexpr int kMaxDesc = 15;   // at most kMaxDesc + 1 = 16 runs are merged; more: a full sort
+constexpr int kMaxRuns = kMaxDesc + 1;
 
 struct OrderSpec {
   int64_t n;
@@ -142,6 +150,9 @@ struct OrderBuffers {
   int64_t *tile_bounds;          // [tiles + 1] first bucket start at or after every tile's first row
   int64_t max_buckets;
   const int32_t *run_if;         // host-side switch: non-null while the stand-by passes are enqueued
+  int n_runs;                    // sorted mode 3: the runs found by the range scan ...
+  int64_t run_start[17];         // ... run r = rows [run_start[r], run_start[r + 1])
+  int64_t *run_cuts;             // [tiles + 1][kMaxRuns] rows of every run before each output tile
   uint64_t *carry[2 * 4];        // [column][2] ping-pong copies of payload columns that travel with the rows
   int carry_cols;
 };
@@ -177,7 +188,12 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
                 OrderResult *res, hipStream_t st, int n_pay = 0,
                 const uint64_t *const *pay_src = nullptr, uint64_t *const *pay_out = nullptr,
                 bool *carried = nullptr);
-inline int sorted_mode(const RangeInfo &r) { return !r.unsorted ? 1 : (!r.time_unsorted ? 2 : 0); }
+// 3 = a few time-ordered runs end to end: merged by time first, then as 2.
+inline int sorted_mode(const RangeInfo &r) {
+  if (!r.unsorted) return 1;
+  if (!r.time_unsorted) return 2;
+  return (r.n_desc >= 1 && r.n_desc <= kMaxDesc) ? 3 : 0;
+}
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
                        hipStream_t st, int n_pay = 0, const uint64_t *const *pay_src = nullptr,
                        uint64_t *const *pay_out = nullptr, bool *carried = nullptr);
@@ -197,11 +213,19 @@ int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_
 int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st);
 
 // floor(a / b), b > 0 expected (negative b falls through to the exact path).  For divisors up
-// to 2^40 the quotient comes from a double-precision estimate that two exact integer
-// remainder steps correct -- a handful of instructions instead of a 64-bit integer division.
+// to 2^40 the quotient comes from a double-precision estimate that exact integer remainder steps
+// correct -- a handful of instructions instead of a 64-bit integer division: one step where
+// 0 <= a < 2^52 (the product is then within one of the quotient), two over the rest of int64.
 __device__ __forceinline__ int64_t floordiv_i64(int64_t a, int64_t b) {
   if (b >= 2 && b <= (1ll << 40)) {
     const double inv = 1.0 / (double)b;
+    if ((uint64_t)a < (1ull << 52)) {
+      int64_t q = (int64_t)((double)a * inv);
+      const int64_t r = a - q * b;
+      if (r < 0) --q;
+      else if (r >= b) ++q;
+      return q;
+    }
     // estimate: off by at most ~2^11 / b + 1 over the whole int64 range
     int64_t q = (int64_t)floor((double)a * inv);
     int64_t r = (int64_t)((uint64_t)a - (uint64_t)q * (uint64_t)b);  // exact: |r| < 2^52

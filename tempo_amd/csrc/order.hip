@@ -50,6 +50,27 @@ __global__ void range_init_kernel(RangeInfo *r) {
   r->time_unsorted = 0;
   r->not_thousands = 0;
   r->not_millions = 0;
+  r->n_desc = 0;
+  r->pad_ = 0;
+  for (int i = 0; i < kMaxDesc; ++i) r->desc_pos[i] = 0;
+}
+
+// Rows of this wave's current step at which time steps back (`down`): counted, and the first few
+// noted, while the count is still small enough to matter (a table in random order stops touching
+// the counter after the first waves).
+__device__ __forceinline__ void note_descents(bool down, int64_t i, RangeInfo *out) {
+  const uint64_t bal = __ballot(down);
+  if (!bal) return;
+  const int lane = threadIdx.x & 63;
+  const int first = __ffsll((long long)bal) - 1;
+  int base = kMaxDesc + 1;
+  if (lane == first && __atomic_load_n(&out->n_desc, __ATOMIC_RELAXED) <= kMaxDesc)
+    base = atomicAdd(&out->n_desc, (int)__popcll(bal));
+  base = __shfl(base, first, 64);
+  if (down) {
+    const int slot = base + (int)__popcll(bal & ((1ull << lane) - 1));
+    if (slot < kMaxDesc) out->desc_pos[slot] = i;
+  }
 }
 
 __device__ __forceinline__ int64_t wave_min(int64_t v) {
@@ -107,6 +128,7 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
         for (int j = 0; j < 4; ++j) t[j] = floordiv_i64(t[j], div);
       }
       if (c == 0) tp = t[0];
+      bool down[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (gran) {
@@ -120,8 +142,13 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
         bad |= kp != kk[j] ? kp > kk[j] : tdown;
         tp = t[j];
         kp = kk[j];
+        down[j] = tdown;
       }
       if (gran && __any(nk)) gran = false;
+      if (__any(down[0] | down[1] | down[2] | down[3])) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) note_descents(down[j], 4 * c + j, out);
+      }
     }
   }
   for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -143,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
         smax = s > smax ? s : smax;
       }
     }
+    bool down = false;
     if (i > 0) {  // lexicographic (key, primary, seq NULLS FIRST) against the previous row
       int32_t k0 = key ? key[i - 1] : 0, k1 = key ? key[i] : 0;
       int64_t p0 = div == 1 ? ts[i - 1] : floordiv_i64(ts[i - 1], div);
@@ -156,9 +184,11 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
         }
       }
       tbad |= tcmp > 0;
+      down = tcmp > 0;
       if (k0 != k1) bad |= k0 > k1;
       else bad |= tcmp > 0;
     }
+    if (__any(down)) note_descents(down, i, out);
   }
   pmin = wave_min(pmin);
   pmax = wave_max(pmax);
@@ -232,6 +262,22 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   for (int m = 0; m < g.n_masks; ++m)
     if (!g.masks.p[m] || g.masks.p[m][i]) w |= 1ull << m;
   return w;
+}
+
+// The (time, sequence) part of row i's sort word, as a number: ordering by it is ordering by
+// (primary, seq NULLS FIRST).  Not for layouts with seq_wide.
+__device__ __forceinline__ uint64_t time_of(const Layout &lay, int64_t ts, bool seq_ok, int64_t seq) {
+  int64_t p = lay.prim_div == 1 ? ts : floordiv_i64(ts, lay.prim_div);
+  uint64_t rel = (uint64_t)(p - lay.prim_min);
+  if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
+  uint64_t t = rel << lay.seq_bits;
+  if (seq_ok) t |= (uint64_t)(seq - lay.seq_min + 1);
+  return t;
+}
+__device__ __forceinline__ uint64_t make_time(const GenArgs &g, int64_t i) {
+  const bool has_seq = g.lay.seq_bits && g.seq;
+  const bool sv = has_seq && (!g.seq_valid || g.seq_valid[i]);
+  return time_of(g.lay, g.ts[i], sv, sv ? g.seq[i] : 0);
 }
 
 // Sort words of the four rows i .. i + 3 (i a multiple of 4, all four inside the table), with
@@ -880,36 +926,166 @@ __global__ __launch_bounds__(kBlock) void tile_bounds_kernel(const uint64_t *w, 
   if (lane == 0) bounds[g] = found;
 }
 
+// ---- a few time-ordered runs laid end to end (sorted mode 3) ---------------------------------
+// The runs are merged by (time, sequence), ties in input order, TS_CAP output rows per tile: for
+// every tile boundary d = t * TS_CAP the cut (c_0 .. c_R-1), sum = d, says how many rows of every
+// run come before it.  It is found by bisecting on the time value v of the d-th merged row --
+// "how many rows are <= v" is one binary search per run, run r in lane r of the wave that owns the
+// boundary -- and handing the rows equal to v out in run order.  Every 64th boundary is searched
+// over whole runs; the ones in between only between their two neighbours' cuts.
+struct RunArgs {
+  int n_runs;
+  int64_t start[kMaxRuns + 1];
+};
+constexpr int kCutStride = 64;
+
+// rows of [base + lo, base + hi) -- time-ordered -- whose time is < v (le false) or <= v (le true), plus lo
+__device__ __forceinline__ int64_t run_rank(const GenArgs &g, int64_t base, int64_t lo, int64_t hi, uint64_t v, bool le) {
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    const uint64_t t = make_time(g, base + mid);
+    if (le ? t <= v : t < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void run_cuts_kernel(GenArgs g, RunArgs ra, int64_t n, int tile, int64_t n_tiles,
+                                                          int fine, int64_t *cuts) {
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  // coarse launch: boundaries 0, 64, 128, ... and the last one; fine launch: all the others
+  int64_t t;
+  if (!fine) {
+    const int64_t n_coarse = (n_tiles + kCutStride - 1) / kCutStride + 1;
+    if (wv >= n_coarse) return;
+    t = wv * kCutStride < n_tiles ? wv * kCutStride : n_tiles;
+  } else {
+    if (wv > n_tiles) return;
+    t = wv;
+    if (t % kCutStride == 0 || t == n_tiles) return;
+  }
+  const bool act = lane < ra.n_runs;
+  const int64_t base = act ? ra.start[lane] : 0;
+  const int64_t len = act ? ra.start[lane + 1] - base : 0;
+  const int64_t d = t * tile < n ? t * tile : n;
+  int64_t lo = 0, hi = len;
+  if (fine) {
+    const int64_t t0 = t / kCutStride * kCutStride;
+    const int64_t t1 = t0 + kCutStride < n_tiles ? t0 + kCutStride : n_tiles;
+    if (act) { lo = cuts[t0 * kMaxRuns + lane]; hi = cuts[t1 * kMaxRuns + lane]; }
+  }
+  int64_t cut = lo;
+  if (d >= n) {
+    cut = len;
+  } else if (d > 0) {
+    // the d-th merged row's time lies between the smallest time at the lower cuts and the largest
+    // before the upper cuts
+    uint64_t vlo = ~0ull, vhi = 0ull;
+    if (act && lo < len) vlo = make_time(g, base + lo);
+    if (act && hi > 0) vhi = make_time(g, base + hi - 1);
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t a = __shfl_xor(vlo, o, 64), b = __shfl_xor(vhi, o, 64);
+      vlo = a < vlo ? a : vlo;
+      vhi = b > vhi ? b : vhi;
+    }
+    while (vlo < vhi) {  // smallest v with (rows <= v) > d
+      const uint64_t mid = vlo + ((vhi - vlo) >> 1);
+      const int64_t mine = act ? run_rank(g, base, lo, hi, mid, true) : 0;
+      // the counts are monotone in v: each answer also narrows where the next search has to look
+      if (wave_sum_i64(mine) > d) { vhi = mid; hi = mine; }
+      else { vlo = mid + 1; lo = mine; }
+    }
+    const int64_t lt = act ? run_rank(g, base, lo, hi, vlo, false) : 0;
+    const int64_t le = act ? run_rank(g, base, lo, hi, vlo, true) : 0;
+    const int64_t rem = d - wave_sum_i64(lt);  // rows equal to v that still come before the boundary
+    int64_t cap = le - lt, inc = cap;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    const int64_t before = inc - cap;  // equal rows of earlier runs
+    int64_t take = rem - before;
+    take = take < 0 ? 0 : (take > cap ? cap : take);
+    cut = lt + take;
+  }
+  if (lane < kMaxRuns) cuts[t * kMaxRuns + lane] = act ? cut : 0;
+}
+
 // TS_BINS bins for the interpolation placement of a tile, two 16-bit counters per LDS word.
 constexpr int TS_BINS = TS_CAP / 2;
 constexpr int TS_DENSE = 64;  // a bin with more slots than this sends its tile to the radix passes
 
-template <int NT, int NI>
+// MERGE: the tile's rows are not one stretch of bucketed pairs but the slices of a few time-ordered
+// runs between two cuts (run_cuts_kernel); they are read from the table's own columns, sorted by
+// (time, sequence) -- ties in input order, as the slots are filled run by run -- and written out as
+// sort words (key included) and row ids.
+template <int NT, int NI, bool MERGE>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, const uint32_t *idin, uint64_t *wout,
                                                        uint32_t *idout, int64_t n, int top_shift, int low_bits,
                                                        const uint32_t *bucket_key, const int64_t *bounds,
-                                                       int32_t *fallback, PayPtrs pp, int force_radix) {
+                                                       int32_t *fallback, PayPtrs pp, int force_radix, GenArgs gen,
+                                                       RunArgs ra) {
   constexpr int CAP = NT * NI, TILE = CAP / 2, NW = NT / 64;
   static_assert(NW * 256 * 4 == TS_BINS * 2 && CAP == TS_CAP, "aux serves both the radix counters and the bins");
   __shared__ uint64_t sbuf[CAP];
   __shared__ uint32_t aux[NW * 256];  // radix passes: [wave][digit] counters; placement: packed bins
   __shared__ uint32_t dstart[256];
   __shared__ uint32_t wtot[NW];
-  __shared__ uint64_t red_min[NW], red_max[NW];
+  __shared__ uint64_t red_min[1], red_max[1];
   __shared__ int dense_s;
   uint32_t(*whist)[256] = reinterpret_cast<uint32_t(*)[256]>(aux);
   uint32_t *sbuf32 = reinterpret_cast<uint32_t *>(sbuf);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const int64_t t0 = (int64_t)blockIdx.x * TILE;
-  const int64_t t1 = t0 + TILE < n ? t0 + TILE : n;
-  // the block owns the buckets that start in [t0, t1): rows [s, e)
-  const int64_t s = bounds[blockIdx.x];
-  if (s >= t1) return;  // a bucket that began earlier covers the whole stretch
-  const int64_t e = bounds[blockIdx.x + 1];
-  if (e == INT64_MAX || e - s > CAP) {
-    if (tid == 0) atomicOr(fallback, 1);
-    return;
+  __shared__ int64_t run_src[kMaxRuns];  // MERGE: first row of every run's slice ...
+  __shared__ int run_off[kMaxRuns + 1];  // ... and the slot its slice starts at
+  int64_t s, e;
+#ifdef TS_TIMING
+  long long tk[16]; int ntk = 0;
+#define TICK() do { __syncthreads(); tk[ntk++] = clock64(); } while (0)
+#else
+#define TICK() do {} while (0)
+#endif
+  TICK();
+  if (tid == 0) { red_min[0] = ~0ull; red_max[0] = 0ull; }
+  if (MERGE) {
+    // bounds = the cuts: tile t holds, of run r, the rows cuts[t][r] .. cuts[t + 1][r]
+    s = (int64_t)blockIdx.x * CAP;
+    e = s + CAP < n ? s + CAP : n;
+    if (tid < 64) {
+      const bool act = tid < ra.n_runs;
+      const int64_t c0 = act ? bounds[(int64_t)blockIdx.x * kMaxRuns + tid] : 0;
+      const int64_t c1 = act ? bounds[((int64_t)blockIdx.x + 1) * kMaxRuns + tid] : 0;
+      int len = (int)(c1 - c0), inc = len;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += up;
+      }
+      if (tid < kMaxRuns) {
+        run_src[tid] = act ? ra.start[tid] + c0 : 0;
+        run_off[tid] = inc - len;
+      }
+      if (tid == kMaxRuns - 1) run_off[kMaxRuns] = inc;
+    }
+    __syncthreads();
+  } else {
+    const int64_t t0 = (int64_t)blockIdx.x * TILE;
+    const int64_t t1 = t0 + TILE < n ? t0 + TILE : n;
+    // the block owns the buckets that start in [t0, t1): rows [s, e)
+    s = bounds[blockIdx.x];
+    if (s >= t1) return;  // a bucket that began earlier covers the whole stretch
+    e = bounds[blockIdx.x + 1];
+    if (e == INT64_MAX || e - s > CAP) {
+      if (tid == 0) atomicOr(fallback, 1);
+      return;
+    }
+    __syncthreads();
   }
   const int m = (int)(e - s);
   // wave w works on slots [w * chunk, (w + 1) * chunk), nit items per lane
@@ -918,42 +1094,180 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
   const uint64_t field_mask = (top_shift >= 64) ? ~0ull : ((1ull << top_shift) - 1);
   uint64_t wv[NI];
   uint32_t idv[NI];
+  uint32_t kv[MERGE ? NI : 1];  // MERGE: key id and NULL flags of the row, as they sit below the time
+  const int kv_bits = MERGE ? gen.lay.key_bits + gen.n_masks : 0;
   uint64_t mn = ~0ull, mx = 0ull;
   if (tid == 0) dense_s = force_radix;
+  // the loads of all the thread's slots are issued before anything is computed from them
+  if (MERGE) {
+    const bool has_seq = gen.lay.seq_bits && gen.seq;
+    const bool has_kv = kv_bits <= 31;  // bit 31 of kv: the row's sequence value is not NULL
+    const bool has_key = gen.lay.key_bits && gen.key && has_kv;
+    TICK();
+    // slot -> row: a lane's slots are 64 apart and mostly inside one run's slice, where the rows
+    // are 64 apart too; the run is looked up again only when some lane of the wave leaves its slice
+    {
+      int next_off = 0;       // slot at which the lane's current slice ends
+      int64_t row_minus = 0;  // row of slot j = row_minus + j inside the current slice
 #pragma unroll
-  for (int it = 0; it < NI; ++it) {
-    wv[it] = 0;
-    idv[it] = 0;
-    const int j = wave * chunk + it * 64 + lane;
-    if (it < nit && j < m) {
-      const uint64_t w = win[s + j];
-      idv[it] = idin[s + j];
-      const uint64_t top = bucket_key ? (uint64_t)bucket_key[w >> top_shift] : (w >> top_shift);
-      const uint64_t v = top_shift >= 64 ? w : ((top << top_shift) | (w & field_mask));
-      wv[it] = v;
-      mn = v < mn ? v : mn;
-      mx = v > mx ? v : mx;
+      for (int it = 0; it < NI; ++it) {
+        const int j = wave * chunk + it * 64 + lane;
+        const bool live = it < nit && j < m;
+        kv[it] = 0;
+        if (__any(live && j >= next_off)) {
+          // the last run whose slice starts at or before slot j (slices of unused runs start at the end)
+          static_assert(kMaxRuns == 16, "four halving steps");
+          const int jj = live ? j : 0;
+          int r = jj >= run_off[8] ? 8 : 0;
+          r += jj >= run_off[r + 4] ? 4 : 0;
+          r += jj >= run_off[r + 2] ? 2 : 0;
+          r += jj >= run_off[r + 1] ? 1 : 0;
+          row_minus = run_src[r] - run_off[r];
+          next_off = run_off[r + 1];
+        }
+        idv[it] = live ? (uint32_t)(row_minus + j) : 0u;
+      }
+    }
+    TICK();
+    // no branch around a load (an unused slot reads row 0): loads inside per-slot branches would
+    // each be waited for before the next is issued
+#pragma unroll
+    for (int it = 0; it < NI; ++it) wv[it] = (uint64_t)gen.ts[idv[it]];
+    if (has_key) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it) kv[it] = (uint32_t)gen.key[idv[it]] << gen.n_masks;
+    }
+    if (has_kv) {
+      for (int mk = 0; mk < gen.n_masks; ++mk) {
+        const uint8_t *mp = gen.masks.p[mk];
+        if (mp) {
+#pragma unroll
+          for (int h = 0; h < NI; h += NI / 2) {  // two batches, to bound the registers held at once
+            uint8_t f[NI / 2];
+#pragma unroll
+            for (int it = 0; it < NI / 2; ++it) f[it] = mp[idv[h + it]];
+#pragma unroll
+            for (int it = 0; it < NI / 2; ++it) kv[h + it] |= (f[it] ? 1u : 0u) << mk;
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < NI; ++it) kv[it] |= 1u << mk;
+        }
+      }
+    }
+    if (has_seq) {
+      if (gen.seq_valid) {
+        uint8_t f[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) f[it] = gen.seq_valid[idv[it]];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) kv[it] |= (f[it] ? 1u : 0u) << 31;
+      } else {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) kv[it] |= 1u << 31;
+      }
+    }
+    TICK();
+    {
+      // floor(ts / prim_div) - prim_min in double arithmetic where that is exact (times below 2^52,
+      // a result below 2^31): product, truncation, and one fused remainder that says whether the
+      // truncated quotient is one off -- a fraction of the instructions of the integer route
+      const Layout &lay = gen.lay;
+      const bool quick = lay.prim_div >= 2 && lay.prim_div <= (1ll << 40) && lay.prim_gran == 1 && lay.prim_bits <= 31;
+      const double bd = (double)lay.prim_div, inv = 1.0 / bd, pmin = (double)lay.prim_min;
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int64_t ts = (int64_t)wv[it];
+        if (quick && (uint64_t)ts < (1ull << 52)) {
+          const double a = (double)ts;
+          double q = trunc(a * inv);
+          const double r = __builtin_fma(-q, bd, a);
+          q += r < 0.0 ? -1.0 : (r >= bd ? 1.0 : 0.0);
+          wv[it] = (uint64_t)(uint32_t)(q - pmin) << lay.seq_bits;
+        } else {
+          wv[it] = time_of(lay, ts, false, 0);
+        }
+      }
+    }
+    TICK();
+    if (has_seq) {
+      // the sequence values join in two batches, to bound the registers held at once
+#pragma unroll
+      for (int h = 0; h < NI; h += NI / 2) {
+        int64_t sq[NI / 2];
+#pragma unroll
+        for (int it = 0; it < NI / 2; ++it) sq[it] = gen.seq[idv[h + it]];
+#pragma unroll
+        for (int it = 0; it < NI / 2; ++it)
+          if (kv[h + it] >> 31) wv[h + it] |= (uint64_t)(sq[it] - gen.lay.seq_min + 1);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      kv[it] &= 0x7fffffffu;
+      if (it < nit && j < m) {
+        mn = wv[it] < mn ? wv[it] : mn;
+        mx = wv[it] > mx ? wv[it] : mx;
+      }
+    }
+  } else {
+    uint32_t top[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      const bool live = it < nit && j < m;
+      wv[it] = live ? win[s + j] : 0ull;
+      idv[it] = live ? idin[s + j] : 0u;
+    }
+    if (bucket_key && top_shift < 64) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = wave * chunk + it * 64 + lane;
+        top[it] = (it < nit && j < m) ? bucket_key[wv[it] >> top_shift] : 0u;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int j = wave * chunk + it * 64 + lane;
+      if (it < nit && j < m) {
+        uint64_t v = wv[it];
+        if (bucket_key && top_shift < 64) v = ((uint64_t)top[it] << top_shift) | (v & field_mask);
+        wv[it] = v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+      }
     }
   }
+  TICK();
   for (int o = 32; o > 0; o >>= 1) {
     const uint64_t a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
     mn = a < mn ? a : mn;
     mx = b > mx ? b : mx;
   }
-  if (lane == 0) { red_min[wave] = mn; red_max[wave] = mx; }
+  if (lane == 0) {
+    atomicMin((unsigned long long *)&red_min[0], (unsigned long long)mn);
+    atomicMax((unsigned long long *)&red_max[0], (unsigned long long)mx);
+  }
   for (int i = tid; i < NW * 256; i += NT) aux[i] = 0;
   __syncthreads();
   mn = red_min[0]; mx = red_max[0];
-  for (int i = 1; i < NW; ++i) {
-    mn = red_min[i] < mn ? red_min[i] : mn;
-    mx = red_max[i] > mx ? red_max[i] : mx;
+  // MERGE: key and flags ride below the time value where the tile's time span leaves room for them
+  // (they are then read with the time, in row order); otherwise they are fetched by row id at the end
+  bool ride = false;
+  const uint64_t tmin = MERGE ? mn : 0ull;  // MERGE: times count from the tile's first
+  if (MERGE) {
+    const int tspan = mx == mn ? 0 : 64 - __clzll((long long)(mx - mn));
+    ride = kv_bits <= 31 && tspan + kv_bits + TS_IDX_BITS <= 64;
+    if (ride) low_bits = kv_bits;
+    mx = (mx - mn) << low_bits;
+    mn = 0;
   }
   const uint64_t low_mask = (1ull << low_bits) - 1;
   const uint64_t wmin = mn & ~low_mask;
   // bits in which the tile's words differ, above the low bits that are carried but not compared
   const uint64_t range = (mx - wmin) >> low_bits;
-  int span = 0;
-  for (uint64_t d = range; d; d >>= 1) ++span;
+  const int span = range ? 64 - __clzll((long long)range) : 0;
   if (span + low_bits + TS_IDX_BITS > 64) {  // no room for the slot number next to the word
     if (tid == 0) atomicOr(fallback, 1);
     return;
@@ -963,9 +1277,12 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int j = wave * chunk + it * 64 + lane;
+    if (MERGE) wv[it] = ((wv[it] - tmin) << low_bits) | (ride ? (uint64_t)kv[it] : 0ull);
     wv[it] = ((wv[it] - wmin) << TS_IDX_BITS) | (uint64_t)j;
   }
-  bool dense = force_radix != 0;
+  TICK();
+  // fewer distinct values than a bin may hold per slot: some bin is crowded for certain
+  bool dense = force_radix != 0 || (range + 1) * (uint64_t)TS_DENSE < (uint64_t)m;
   if (!dense && span > 0) {
     // ---- interpolation placement: bin = floor(TS_BINS * value / (range + 1)) is monotone in the
     // value; where the values are spread evenly a bin holds a slot or two.  Count per bin, scan,
@@ -1058,6 +1375,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
       }
     }
   }
+  TICK();
   if (dense || span == 0) {
     // ---- radix passes (values bunched inside the tile, or nothing to sort: one plain copy)
     __syncthreads();
@@ -1077,28 +1395,46 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
       // here, the words stay in LDS until the scatter, so few registers are live while ranking
       uint32_t rk[NI];  // rank | digit << 16, then the slot's destination
 #pragma unroll
+      for (int it = 0; it < NI; ++it) rk[it] = (uint32_t)(sbuf[wave * chunk + it * 64 + lane] >> shift) & 255u;
+#pragma unroll
       for (int it = 0; it < NI; ++it) {
-        rk[it] = 0;
         if (it < nit) {  // wave-uniform
           const int j = wave * chunk + it * 64 + lane;
           const bool valid = j < m;
-          const uint32_t d = valid ? (uint32_t)(sbuf[j] >> shift) & 255u : 0u;
-          const uint64_t vb = __ballot(valid);
-          uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
+          const uint32_t d = valid ? rk[it] : 0u;
+          const uint64_t vb = __ballot(valid);  // the valid lanes are the first ones
+          const uint32_t dprev = (uint32_t)__shfl_up((int)d, 1, 64);
+          uint32_t cnt, before;  // lanes of the wave with this digit, and how many of them come first
+          bool leader;
+          if (__all(!valid || lane == 0 || d >= dprev)) {
+            // digits already in order across the wave (slices of sorted runs): equal digits sit
+            // next to each other, so a lane's peers are the stretch between two changes of digit
+            const uint64_t starts = __ballot(valid && (lane == 0 || d != dprev));
+            const uint64_t upto = lt_mask | (1ull << lane);
+            const int first = 63 - __clzll((long long)(starts & upto));
+            const uint64_t above = (starts | ~vb) & ~upto;
+            const int next = above ? __ffsll((long long)above) - 1 : 64;
+            cnt = (uint32_t)(next - first);
+            before = (uint32_t)(lane - first);
+            leader = valid && lane == first;
+          } else {
+            uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
 #pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
-            const uint64_t bal = __ballot(mb != 0u);
-            plo &= ~((uint32_t)bal ^ mb);
-            phi &= ~((uint32_t)(bal >> 32) ^ mb);
+            for (int b = 0; b < 8; ++b) {
+              const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or ~0
+              const uint64_t bal = __ballot(mb != 0u);
+              plo &= ~((uint32_t)bal ^ mb);
+              phi &= ~((uint32_t)(bal >> 32) ^ mb);
+            }
+            const uint64_t peers = ((uint64_t)phi << 32) | plo;
+            cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+            before = (uint32_t)__popcll(peers & lt_mask);
+            leader = valid && (lane == (__ffsll((long long)peers) - 1));
           }
-          const uint64_t peers = ((uint64_t)phi << 32) | plo;
           uint32_t prior = __hip_atomic_load(&whist[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          const uint32_t cnt = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
-          const bool leader = valid && (lane == (__ffsll((long long)peers) - 1));
           if (leader)
             __hip_atomic_store(&whist[wave][d], prior + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          rk[it] = (prior + (uint32_t)__popcll(peers & lt_mask)) | (d << 16);
+          rk[it] = (prior + before) | (d << 16);
         }
       }
       __syncthreads();
@@ -1128,11 +1464,9 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
         const int j = wave * chunk + it * 64 + lane;
-        if (it < nit && j < m) {
-          const uint32_t d = rk[it] >> 16;
-          wv[it] = sbuf[j];
-          rk[it] = dstart[d] + whist[wave][d] + (rk[it] & 0xffffu);
-        }
+        const uint32_t d = (rk[it] >> 16) & 255u;
+        wv[it] = sbuf[j];
+        rk[it] = dstart[d] + whist[wave][d] + (rk[it] & 0xffffu);
       }
       __syncthreads();
 #pragma unroll
@@ -1143,6 +1477,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
     }
   }
   __syncthreads();
+  TICK();
   // ---- out: words in order; the row ids change places through the same buffer
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
@@ -1158,12 +1493,24 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
   __syncthreads();
   const uint64_t idx_mask = (1ull << TS_IDX_BITS) - 1;
 #pragma unroll
+  for (int it = 0; it < NI; ++it) idv[it] = sbuf32[(uint32_t)(wv[it] & idx_mask)];
+#pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int j = tid + it * NT;
     if (j < m) {
       const uint64_t pk = wv[it];
-      wout[s + j] = (pk >> TS_IDX_BITS) + wmin;
-      const uint32_t id = sbuf32[(uint32_t)(pk & idx_mask)];
+      const uint32_t id = idv[it];
+      uint64_t w = (pk >> TS_IDX_BITS) + wmin;
+      if (MERGE) {
+        if (ride) {
+          const uint64_t x = w & low_mask;
+          w = (((w >> low_bits) + tmin) << gen.lay.seq_shift()) | (x & ((1ull << gen.n_masks) - 1));
+          if (gen.lay.key_bits) w |= (x >> gen.n_masks) << gen.lay.key_shift();
+        } else {
+          w = make_word(gen, (int64_t)id);
+        }
+      }
+      wout[s + j] = w;
       idout[s + j] = id;
       const uint64_t from = pp.positional ? (uint64_t)(s + (int64_t)(pk & idx_mask)) : (uint64_t)id;
 #pragma unroll
@@ -1171,6 +1518,17 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
         if (c < pp.n) pp.out[c][s + j] = pp.src[c][from];
     }
   }
+  TICK();
+#ifdef TS_TIMING
+  if (tid == 0 && (blockIdx.x % 9973) == 500)
+    if (ntk >= 10) {
+      printf("M tile %d m %d dense %d: cuts %lld lookup %lld loads %lld time_of %lld rest %lld minmax %lld interp %lld radix %lld out %lld\n", (int)blockIdx.x, m, (int)dense,
+           tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6], tk[8] - tk[7], tk[9] - tk[8]);
+    } else {
+      printf("S tile %d m %d dense %d: load %lld minmax %lld interp %lld radix %lld out %lld\n", (int)blockIdx.x, m, (int)dense,
+           tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+    }
+#endif
 }
 
 // Copies the stand-by sort's result to where the tile kernel would have left it (only when the
@@ -1236,13 +1594,15 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, int c
   b->run_if = nullptr;
   b->carry_cols = 0;
   for (int c = 0; c < 2 * kMaxPay; ++c) b->carry[c] = nullptr;
+  b->n_runs = 0;
+  b->run_cuts = ws.take<int64_t>((size_t)(n / TS_CAP + 3) * kMaxRuns);
+  b->fallback = ws.take<int32_t>(1);
   const BucketGeom g = bucket_geometry(n, n_keys);
   if (g.ok) {
     b->key_rows = ws.take<unsigned long long>((size_t)n_keys);
     b->key_nb = ws.take<uint32_t>((size_t)n_keys);
     b->key_base = ws.take<uint32_t>((size_t)n_keys);
     b->bucket_key = ws.take<uint32_t>((size_t)g.max_buckets);
-    b->fallback = ws.take<int32_t>(1);
     b->tile_bounds = ws.take<int64_t>((size_t)(n / TS_TILE + 3));
     b->max_buckets = g.max_buckets;
     b->carry_cols = carry_cols < kMaxPay ? carry_cols : kMaxPay;
@@ -1264,6 +1624,17 @@ int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
 int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st) {
   TMP_CHECK_HIP(hipMemcpyAsync(host, b.range, sizeof(RangeInfo), hipMemcpyDeviceToHost, st));
   TMP_CHECK_HIP(hipStreamSynchronize(st));
+  b.n_runs = 0;
+  if (sorted_mode(*host) == 3) {  // a few time-ordered runs end to end: where each starts
+    int64_t pos[kMaxDesc];
+    const int d = host->n_desc;
+    for (int i = 0; i < d; ++i) pos[i] = host->desc_pos[i];
+    for (int i = 1; i < d; ++i)  // insertion sort of at most 15 positions
+      for (int j = i; j > 0 && pos[j - 1] > pos[j]; --j) { int64_t t = pos[j]; pos[j] = pos[j - 1]; pos[j - 1] = t; }
+    b.n_runs = d + 1;
+    b.run_start[0] = 0;
+    for (int i = 0; i < d; ++i) b.run_start[i + 1] = pos[i];
+  }
   return TMP_OK;
 }
 
@@ -1490,6 +1861,40 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     TMP_CHECK_HIP(hipGetLastError());
     return TMP_OK;
   }
+  if (sorted == 3 && (lay.seq_wide || !b.run_cuts || b.n_runs < 2 || b.n_runs > kMaxRuns ||
+                      lay.prim_bits + lay.seq_bits + TS_IDX_BITS > 64))
+    sorted = 0;
+  if (sorted == 3) {
+    // a few time-ordered runs end to end: merged by (time, sequence) tile by tile straight from the
+    // table's columns, then -- like any time-ordered feed -- stable passes over the key bits alone
+    RunArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.n_runs = b.n_runs;
+    for (int r = 0; r < b.n_runs; ++r) ra.start[r] = b.run_start[r];
+    ra.start[b.n_runs] = s.n;
+    const int64_t n_tiles = (s.n + TS_CAP - 1) / TS_CAP;
+    const int64_t n_coarse = (n_tiles + kCutStride - 1) / kCutStride + 1;
+    TMP_LAUNCH(run_cuts_kernel, dim3((unsigned)((n_coarse + 3) / 4)), dim3(kBlock), st, gen, ra, s.n, TS_CAP, n_tiles, 0,
+               b.run_cuts);
+    TMP_LAUNCH(run_cuts_kernel, dim3((unsigned)((n_tiles + 1 + 3) / 4)), dim3(kBlock), st, gen, ra, s.n, TS_CAP, n_tiles, 1,
+               b.run_cuts);
+    PayPtrs none;
+    memset(&none, 0, sizeof(none));
+    {
+      ProfScope ps("tile_merge_kernel", st);
+      hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS, true>), dim3((unsigned)n_tiles), dim3(TS_THREADS), 0, st,
+                         (const uint64_t *)nullptr, (const uint32_t *)nullptr, b.comp[1], b.idx[1], s.n, 64, 0,
+                         (const uint32_t *)nullptr, b.run_cuts, b.fallback, none, 0, gen, ra);
+    }
+    TMP_CHECK_HIP(hipGetLastError());
+    if (lay.key_shift() >= hi_bit) {  // no key: the merged order is the result
+      res->comp = b.comp[1];
+      res->perm = b.idx[1];
+      return TMP_OK;
+    }
+    return radix_passes(b, s.n, lay.key_shift(), hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr, nullptr,
+                        nullptr, 1);
+  }
   if (lay.seq_wide && s.seq && sorted == 0) {
     // the sequence values first (stable passes over words that hold nothing else), then the sort
     // words -- laid out in the order those passes left, through the row ids -- over their own bits
@@ -1546,9 +1951,11 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
              lay.key_shift(), TS_TILE, TS_CAP, n_tiles, b.tile_bounds);
   {
     ProfScope ps("tile_sort_kernel", st);
-    hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS>), dim3((unsigned)n_tiles), dim3(TS_THREADS), 0, st,
+    RunArgs no_runs;
+    memset(&no_runs, 0, sizeof(no_runs));
+    hipLaunchKernelGGL((tile_sort_kernel<TS_THREADS, TS_ITEMS, false>), dim3((unsigned)n_tiles), dim3(TS_THREADS), 0, st,
                        b.comp[at], b.idx[at], b.comp[at ^ 1], b.idx[at ^ 1], s.n, lay.key_shift(), lay.low_bits,
-                       b.bucket_key, b.tile_bounds, b.fallback, pp, getenv("TEMPO_TILE_RADIX") ? 1 : 0);
+                       b.bucket_key, b.tile_bounds, b.fallback, pp, getenv("TEMPO_TILE_RADIX") ? 1 : 0, gen, no_runs);
   }
   TMP_CHECK_HIP(hipGetLastError());
   // ---- stand-by: the plain passes, every kernel of which returns at once unless a tile gave up

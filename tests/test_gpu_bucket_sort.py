@@ -100,3 +100,61 @@ def test_bucketed_default_threshold_at_six_million_rows(monkeypatch):
     word = (key.to(torch.int64) << 40) | (ts - BASE)
     want = torch.sort(word, stable=True).indices.to(torch.int32)
     assert torch.equal(perm, want)
+
+
+def _runs_table(rng, n, n_runs, n_keys, span_us, step_us):
+    """n rows in n_runs time-ordered runs laid end to end (keys interleaved inside a run): what a
+    rank holds after the key shuffle of time-ordered feeds."""
+    key = rng.integers(0, n_keys, n).astype(np.int32)
+    ts = BASE + rng.integers(0, span_us // step_us + 1, n) * step_us
+    cuts = np.sort(rng.choice(np.arange(1, n), n_runs - 1, replace=False)) if n_runs > 1 else np.array([], int)
+    bounds = np.r_[0, cuts, n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ts[a:b] = np.sort(ts[a:b], kind="stable")
+    return key, ts
+
+
+@pytest.mark.parametrize("n,n_runs,n_keys,span_s,step_us", [
+    (200_000, 8, 100, 3000, 1),             # many rows per second once the seconds cast applies
+    (150_001, 2, 7, 50, 1_000_000),         # heavy duplicates: 50 distinct times
+    (70_000, 16, 1, 10_000, 1000),          # the most runs merged, a single series
+    (9_000, 5, 40, 600, 1),                 # less than one tile
+    (120_000, 17, 30, 3000, 1),             # one run too many: the full sort takes over
+])
+@pytest.mark.parametrize("floor_seconds", [False, True])
+def test_time_ordered_runs_are_merged(orc, monkeypatch, n, n_runs, n_keys, span_s, step_us, floor_seconds):
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(n + n_runs)
+    key, ts = _runs_table(rng, n, n_runs, n_keys, span_s * 1_000_000, step_us)
+    names = _check(orc, key, ts, n_keys, floor_seconds=floor_seconds) if floor_seconds else _check(orc, key, ts, n_keys)
+    # rows that happen to be in time order across a run boundary merge two runs into one: fewer, never more
+    assert ("tile_merge_kernel" in names) == (n_runs <= 16), sorted(names)
+
+
+def test_time_ordered_runs_with_sequence_and_operators(orc, monkeypatch):
+    """Runs whose ties the sequence column breaks (NULLS FIRST), and the operators that sit on the
+    ordering: EMA and withRangeStats on a table of runs equal the oracle's."""
+    from tempo_amd import ops
+    rng = np.random.default_rng(77)
+    n, n_runs, n_keys = 180_000, 6, 25
+    key = rng.integers(0, n_keys, n).astype(np.int32)
+    ts = BASE + rng.integers(0, 2000, n) * 1_000_000
+    seq = rng.integers(0, 50, n)
+    seq_valid = (rng.random(n) >= 0.2).astype(np.uint8)
+    bounds = np.r_[0, np.sort(rng.choice(np.arange(1, n), n_runs - 1, replace=False)), n]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        o = np.lexsort((np.where(seq_valid[a:b] != 0, seq[a:b] + 1, 0), ts[a:b]))
+        for arr in (key, ts, seq, seq_valid):
+            arr[a:b] = arr[a:b][o]
+    names = _check(orc, key, ts, n_keys, seq=seq, seq_valid=seq_valid, floor_seconds=True)
+    assert "tile_merge_kernel" in names
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = rng.normal(0, 1, n)
+    xv = (rng.random(n) >= 0.1).astype(np.uint8)
+    perm, ema = ops.ema(d(key), d(ts), d(x), d(xv), n_keys, window=7, exp_factor=0.3, seq=d(seq), seq_valid=d(seq_valid))
+    operm, oema = orc.ema(key, ts, x, xv, 7, 0.3, seq=seq, seq_valid=seq_valid)
+    assert np.array_equal(perm.cpu().numpy(), operm) and np.array_equal(ema.cpu().numpy(), oema)
+    out = ops.range_stats(d(key), d(ts), d(x), d(xv), n_keys, 30)
+    ref = orc.range_stats(key, ts, x, xv, 30)
+    assert np.array_equal(out["perm"].cpu().numpy(), ref["perm"]) and np.array_equal(out["count"].cpu().numpy(), ref["count"])
+    np.testing.assert_allclose(out["mean"].cpu().numpy(), ref["mean"], rtol=1e-9, atol=1e-12)
