@@ -57,6 +57,31 @@ def join_scenario(out_dir, rank, world):
              right=np.where(idx >= 0, r2n[np.maximum(idx, 0)], -1))
 
 
+def time_split_scenario(out_dir, rank, world):
+    """A table without partition columns (one global series) over time ranges, through the real
+    exchange and all-gather: every rank writes the rows it produced, rank 0 also what the
+    operator gives on the whole table."""
+    import json
+
+    import oracle_ops
+    import timesplit_cases as tc
+    from tempo_amd import timesplit
+    comm = timesplit.GroupComm(partition_fn=host_partition, take_fn=host_take)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    out = {}
+    have, want = tc.check_ema(comm, oracle_ops, T, n=1500, n_keys=1, window=9)
+    out["ema"] = [have, want]
+    have, want = tc.check_join(comm, oracle_ops, T, n=1500, n_keys=2, skip_nulls=True)
+    out["join"] = [have, want]
+    have, want = tc.check_range_stats(comm, oracle_ops, T, n=1500, n_keys=1, window=45)
+    out["range_stats"] = [have, want]
+    if rank != 0:
+        for v in out.values():
+            v[1] = {}
+    with open(os.path.join(out_dir, f"timesplit{rank}.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     out_dir = sys.argv[1]
     if os.environ.get("TEMPO_TEST_MAX_MESSAGE_BYTES"):  # force the exchange into many small rounds
@@ -82,6 +107,7 @@ def main():
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rid=rid_loc.numpy()[r["perm"]], mean=r["mean"],
              count=r["count"], stddev=r["stddev"], mx=r["max"])
     join_scenario(out_dir, rank, world)
+    time_split_scenario(out_dir, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -52,6 +52,22 @@ def test_key_shuffle_two_ranks(tmp_path, orc, max_message_bytes):
         assert (got[:, d["left"]] == -2).all(), "a left row was joined on two ranks"
         got[:, d["left"]] = d["right"]
     assert np.array_equal(got, ref)
+    # one global series cut into time ranges (halo rows, carried tails, carried last right rows)
+    import json
+    parts = [json.load(open(tmp_path / f"timesplit{rank}.json")) for rank in range(2)]
+    for op in ("ema", "join", "range_stats"):
+        want = parts[0][op][1]
+        have = {}
+        for p_ in parts:
+            assert not (have.keys() & p_[op][0].keys()), "a row came out of two ranks"
+            have.update(p_[op][0])
+        assert len(want) == 1500 and all(len(p_[op][0]) > 100 for p_ in parts), "every rank owns a time range"
+        if op == "range_stats":
+            import timesplit_cases as tc
+            assert have.keys() == want.keys()
+            tc.compare_range_stats({k: tuple(v) for k, v in have.items()}, {k: tuple(v) for k, v in want.items()})
+        else:
+            assert have == want, op
 
 
 def test_assign_owners_balances_and_is_deterministic():

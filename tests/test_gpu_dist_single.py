@@ -267,3 +267,47 @@ def test_partition_move_equals_partition_plus_gather(n, world):
             p = perm.cpu().numpy()[:m]
             for c, o in zip(cols, outs):
                 assert np.array_equal(o.cpu().numpy()[:m], c[p])
+
+
+@pytest.mark.parametrize("n_keys", [1, 3])
+def test_time_ranges_equal_single_gpu(orc, n_keys):
+    """A table without partition columns (one global series; and one with three hot keys) over 8
+    simulated ranks that own consecutive time ranges: routing kernels, halo / carried rows and the
+    HIP operators per rank; the union of the ranks' results is the operator on the whole table."""
+    import timesplit_cases as tc
+    from tempo_amd import ops, timesplit
+    comm = timesplit.SimComm(8)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    have, want = tc.check_range_stats(comm, ops, T, n=120_000, n_keys=n_keys, window=30)
+    assert have.keys() == want.keys()
+    tc.compare_range_stats(have, want)
+    have, want = tc.check_ema(comm, ops, T, n=100_000, n_keys=n_keys, window=12, with_seq=n_keys > 1)
+    assert have == want
+    have, want = tc.check_lookback(comm, ops, T, n=60_000, n_keys=n_keys, size=6, exact=n_keys == 1)
+    tc.compare_lookback(have, want)
+    for skip_nulls in (True, False):
+        have, want = tc.check_join(comm, ops, T, n=100_000, n_keys=n_keys, skip_nulls=skip_nulls)
+        assert have == want
+
+
+def test_time_ranges_single_rank_nccl(orc):
+    """The same path through a one-rank RCCL group: exchange and all-gather on the device."""
+    import torch.distributed as dist
+    import timesplit_cases as tc
+    from tempo_amd import ops, timesplit
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29580")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        comm = timesplit.GroupComm()
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        have, want = tc.check_ema(comm, ops, T, n=50_000, n_keys=1, window=5)
+        assert have == want
+        have, want = tc.check_join(comm, ops, T, n=50_000, n_keys=2)
+        assert have == want
+    finally:
+        if created:
+            dist.destroy_process_group()
