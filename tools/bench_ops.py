@@ -2,7 +2,10 @@
 resident in HBM).  Prints one JSON line per operator: rows/s, ms per call and the per-kernel
 device time from the library's own launch events.
 
-  python tools/bench_ops.py [--rows 500000000]
+  python tools/bench_ops.py [--rows 500000000] [--reps 3] [--no-profile]
+
+--no-profile leaves the library's own launch events off (for runs under rocprofv3, which times
+and counts the kernels itself).
 """
 import argparse
 import json
@@ -32,7 +35,11 @@ def accelerometer(dev, n, users=9, seed=3456):
     return key, ts, cols, users
 
 
-def timed(fn, reps=3):
+REPS = 3
+
+
+def timed(fn, reps=None):
+    reps = reps or REPS
     fn()
     torch.cuda.synchronize()
     _lib.profile_reset()
@@ -52,9 +59,13 @@ def timed(fn, reps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=500_000_000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
+    global REPS
+    REPS = args.reps
     dev = torch.device("cuda", 0)
-    _lib.profile_enable(True)
+    _lib.profile_enable(not args.no_profile)
     key, ts, cols, nk = accelerometer(dev, args.rows)
     n = ts.numel()
     torch.cuda.synchronize()
@@ -76,6 +87,11 @@ def main():
     m = min(n, 100_000_000)
     ms, kern = timed(lambda: ops.lookback(key[:m], ts[:m], [c[:m] for c in cols], [None] * 3, nk, 10))
     report("withLookbackFeatures(L=10, F=3)", ms, kern, m)
+    # the shuffle's device side: rows routed to 8 owners, key + ts + one fp64 + one flag column moved
+    flag = (cols[1] > 0).to(torch.uint8)
+    ms, kern = timed(lambda: ops.partition_move(key, [key, ts, cols[0], flag], 8))
+    report("shuffle routing (8 owners; key, ts, fp64, flag)", ms, kern, n)
+    del flag
     # interpolate: one-minute means upsampled to one second (60x)
     r = ops.resample(key, ts, nk, 60_000_000, "mean", cols[:1], [None])
     sk, st, sv = r["key"].contiguous(), r["start"].contiguous(), r["f64"][0].contiguous()
