@@ -556,6 +556,70 @@ int tmp_write_layout(const tmp_write_layout_args *a, void *workspace, size_t wor
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Arrow C data interface import: one Arrow array (a column chunk) from host memory into a device
+ * column, straight out of the Arrow buffers -- no pandas / numpy copy in between.
+ *
+ * Replaces the DataFrame hand-over of python/tempo/tsdf.py:24-36 (TSDF.__init__ takes a Spark
+ * DataFrame; Spark hands partitions over as Arrow batches through mapInArrow / toArrow) for the
+ * columns the hot path reads: dictionary-encoded partition keys, timestamp[*] time indices and
+ * numeric metrics.  The structs are the ones the Arrow specification fixes (guarded by the
+ * specification's own macro, so Arrow's header may be included as well).
+ *
+ *   array / schema   an exported array and its type.  Supported storage: int8..int64,
+ *                    uint8..uint64, float32, float64, timestamp[s|ms|us|ns] ("c C s S i I l L f g
+ *                    ts?:..."), and dictionary arrays with integer indices (the indices are
+ *                    imported; the dictionary stays with the caller).  array->offset is honoured.
+ *   out_kind         element type of out_values:
+ *                      TMP_ARROW_I32      int32   (integers, dictionary indices: key ids)
+ *                      TMP_ARROW_I64      int64   (integers; timestamps become microseconds,
+ *                                                  nanoseconds floored)
+ *                      TMP_ARROW_I64_RAW  int64   (timestamps in their own unit)
+ *                      TMP_ARROW_F64      double  (floats and integers)
+ *   out_values       device array of array->length elements; slots that are NULL hold 0
+ *   out_valid        device uint8[length]: 1 = not NULL.  May be NULL when array->null_count == 0.
+ *   out_null_count   host int64, may be NULL: the NULLs of this array (counted from the bitmap
+ *                    when the producer left null_count at -1)
+ * The copies are queued on `stream`; the Arrow buffers must stay alive until the stream has
+ * passed them (synchronise before calling the array's release callback).
+ */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char *format;
+  const char *name;
+  const char *metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema **children;
+  struct ArrowSchema *dictionary;
+  void (*release)(struct ArrowSchema *);
+  void *private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void **buffers;
+  struct ArrowArray **children;
+  struct ArrowArray *dictionary;
+  void (*release)(struct ArrowArray *);
+  void *private_data;
+};
+#endif
+
+#define TMP_ARROW_I32 0
+#define TMP_ARROW_I64 1
+#define TMP_ARROW_F64 2
+#define TMP_ARROW_I64_RAW 3
+
+size_t tmp_arrow_import_workspace_bytes(const struct ArrowArray *array, const struct ArrowSchema *schema);
+int tmp_arrow_import(const struct ArrowArray *array, const struct ArrowSchema *schema, int32_t out_kind,
+                     void *out_values, uint8_t *out_valid, int64_t *out_null_count, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Diagnostics: per-kernel device time (no counterpart in the reference; Spark exposes stage
  * timings through its UI).  While enabled, every kernel launch of the entry points above is
  * bracketed by two HIP events on its launch stream.  tmp_profile_enable(1) creates the event

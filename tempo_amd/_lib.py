@@ -116,6 +116,27 @@ class WriteLayoutArgs(C.Structure):
                 ("out_dt_range", _vp)]
 
 
+class ArrowSchema(C.Structure):
+    """struct ArrowSchema of the Arrow C data interface."""
+
+
+ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", _vp), ("flags", C.c_int64),
+                        ("n_children", C.c_int64), ("children", _vp), ("dictionary", C.POINTER(ArrowSchema)),
+                        ("release", C.CFUNCTYPE(None, C.POINTER(ArrowSchema))), ("private_data", _vp)]
+
+
+class ArrowArray(C.Structure):
+    """struct ArrowArray of the Arrow C data interface."""
+
+
+ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64),
+                       ("n_buffers", C.c_int64), ("n_children", C.c_int64), ("buffers", C.POINTER(_vp)),
+                       ("children", _vp), ("dictionary", C.POINTER(ArrowArray)),
+                       ("release", C.CFUNCTYPE(None, C.POINTER(ArrowArray))), ("private_data", _vp)]
+
+ARROW_I32, ARROW_I64, ARROW_F64, ARROW_I64_RAW = 0, 1, 2, 3
+
+
 # every symbol include/tempo_hip.h declares: name -> (restype, argtypes)
 _OP = lambda argt: (C.c_int, [C.POINTER(argt), _vp, C.c_size_t, _vp])
 _WS = lambda argt: (C.c_size_t, [C.POINTER(argt)])
@@ -150,6 +171,9 @@ SYMBOLS = {
     "tmp_key_owner": (C.c_int32, [C.c_int32, C.c_int32]),
     "tmp_write_layout_workspace_bytes": _WS(WriteLayoutArgs),
     "tmp_write_layout": _OP(WriteLayoutArgs),
+    "tmp_arrow_import_workspace_bytes": (C.c_size_t, [C.POINTER(ArrowArray), C.POINTER(ArrowSchema)]),
+    "tmp_arrow_import": (C.c_int, [C.POINTER(ArrowArray), C.POINTER(ArrowSchema), C.c_int32, _vp, _vp,
+                                   C.POINTER(C.c_int64), _vp, C.c_size_t, _vp]),
     "tmp_profile_enable": (C.c_int, [C.c_int]),
     "tmp_profile_reset": (C.c_int, []),
     "tmp_profile_count": (C.c_int, []),

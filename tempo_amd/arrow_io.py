@@ -2,9 +2,12 @@
 
 What a Spark-side caller (`mapInArrow` / `toArrow` per key-hash partition, or any Arrow
 producer) hands over and takes back for the two headline operators.  Columns go to HBM from
-the Arrow buffers themselves: partition keys are dictionary-encoded by Arrow (one dictionary
-shared by both sides of a join), `timestamp[*]` columns become int64 microseconds, numeric
-columns become float64 / int64 with the Arrow validity bitmap as the NULL mask.
+the Arrow buffers themselves, through the Arrow C data interface (tmp_arrow_import: one
+host-to-device copy per chunk out of Arrow's own buffer, type conversion and the expansion of
+the validity bitmap on the device): partition keys are dictionary-encoded by Arrow (one
+dictionary shared by both sides of a join) and their indices imported, `timestamp[*]` columns
+become int64 microseconds, numeric columns become float64 / int64 with the Arrow validity
+bitmap as the NULL mask.
 
   asof_join(left, right, ...)   TSDF.asofJoin (python/tempo/tsdf.py:463-560) through the fused
                                 device join: the joined table in (key, ts) order
@@ -70,6 +73,34 @@ def encode_keys(tables, cols):
     return parts, n_keys, decode
 
 
+def encode_keys_dev(tables, cols):
+    """encode_keys with the codes on the device: ([int32 device codes per table], n_keys, decode).
+    One partition column: the dictionary indices Arrow computed are imported as they are."""
+    if len(cols) != 1:
+        parts, n_keys, decode = encode_keys(tables, cols)
+        return [None if p is None else col.to_dev(p) for p in parts], n_keys, decode
+    whole = pa.concat_arrays([_combined(t[cols[0]]) for t in tables])
+    enc = pc.dictionary_encode(whole, null_encoding="encode")
+    dictionary, indices = enc.dictionary, enc.indices
+    n_keys = max(len(dictionary), 1)
+    codes, _, _ = ops.arrow_import(indices, "i32")
+    parts, at = [], 0
+    for t in tables:
+        parts.append(codes[at:at + t.num_rows])
+        at += t.num_rows
+    return parts, n_keys, (lambda c: [dictionary.take(pa.array(np.asarray(c, dtype=np.int64), type=pa.int64()))])
+
+
+def timestamps_dev(arr):
+    """(int64 device tensor of microseconds, Arrow type) of a timestamp column, imported from the
+    Arrow buffers (nanoseconds floored, as Spark keeps microseconds); NULLs are rejected."""
+    if not pa.types.is_timestamp(arr.type):
+        raise TypeError(f"time index column must be an Arrow timestamp, got {arr.type}")
+    if arr.null_count:
+        raise ValueError("NULL timestamps are not supported in the time index column")
+    return ops.arrow_import(arr, "i64")[0], arr.type
+
+
 def timestamps_us(arr):
     """(int64 numpy microseconds, Arrow type) of a timestamp column; NULLs are rejected."""
     arr = _combined(arr)
@@ -89,26 +120,22 @@ def timestamps_us(arr):
 def payload_to_device(arr):
     """(8-byte device tensor, uint8 validity tensor or None, decode) for a payload column of the
     fused join: integers, floats, timestamps and dictionary-encodable columns (strings)."""
-    arr = _combined(arr)
-    valid = None
-    if arr.null_count:
-        valid = col.to_dev(pc.is_valid(arr).to_numpy(zero_copy_only=False).astype(np.uint8))
     t = arr.type
-    if pa.types.is_floating(t):
-        vals = pc.fill_null(arr.cast(pa.float64()), 0.0).to_numpy(zero_copy_only=False)
+    if pa.types.is_floating(t) and t != pa.float16():
+        vals, valid, _ = ops.arrow_import(arr, "f64")
         dec = lambda v, ok: pa.array(v, type=pa.float64(), mask=~ok).cast(t)
     elif pa.types.is_integer(t):
-        vals = pc.fill_null(arr.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        vals, valid, _ = ops.arrow_import(arr, "i64")
         dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
     elif pa.types.is_timestamp(t):
-        vals = pc.fill_null(arr.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        vals, valid, _ = ops.arrow_import(arr, "i64_raw")
         dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
     else:
-        enc = pc.dictionary_encode(arr)
-        vals = pc.fill_null(enc.indices.cast(pa.int64()), 0).to_numpy(zero_copy_only=False)
+        enc = pc.dictionary_encode(_combined(arr))
+        vals, valid, _ = ops.arrow_import(enc.indices, "i64")
         dictionary = enc.dictionary
         dec = lambda v, ok: dictionary.take(pa.array(v, type=pa.int64(), mask=~ok))
-    return col.to_dev(np.ascontiguousarray(vals)), valid, dec
+    return vals, valid, dec
 
 
 def _stamps(us, typ):
@@ -120,16 +147,16 @@ def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="r
     """AS-OF join of two Arrow tables.  Returns the joined table ordered by (partition, ts):
     partition columns, the left columns, then `<right_prefix>_<name>` for every right column."""
     partition_cols = list(partition_cols)
-    (key_l, key_r), n_keys, decode_keys = encode_keys([left, right], partition_cols)
-    ts_l, ts_type = timestamps_us(left[ts_col])
-    ts_r, ts_type_r = timestamps_us(right[ts_col])
+    (key_l, key_r), n_keys, decode_keys = encode_keys_dev([left, right], partition_cols)
+    ts_l, ts_type = timestamps_dev(left[ts_col])
+    ts_r, ts_type_r = timestamps_dev(right[ts_col])
     if ts_type != ts_type_r:
         raise ValueError("left and right dataframe timestamp index columns should have same type")
     left_cols = [c for c in left.column_names if c not in partition_cols and c != ts_col]
     right_cols = [c for c in right.column_names if c not in partition_cols]
     lenc = [payload_to_device(left[c]) for c in left_cols]
     renc = [payload_to_device(right[c]) for c in right_cols]
-    j = ops.asof_join_table(col.to_dev(key_l), col.to_dev(ts_l), col.to_dev(key_r), col.to_dev(ts_r), n_keys,
+    j = ops.asof_join_table(key_l, ts_l, key_r, ts_r, n_keys,
                             [t for t, _, _ in lenc], [t for t, _, _ in renc], [v for _, v, _ in renc],
                             skip_nulls=skip_nulls, ts_partition_val=ts_partition_val, fraction=fraction)
     names, arrays = [], []
@@ -159,9 +186,8 @@ def range_stats(table, ts_col="event_ts", partition_cols=(), cols=(), range_back
     """withRangeStats on an Arrow table: the input rows in (partition, ts) order plus
     mean_/count_/min_/max_/sum_/stddev_/zscore_<col> for every column in `cols`."""
     partition_cols = list(partition_cols)
-    (key,), n_keys, _ = encode_keys([table], partition_cols)
-    ts, _ = timestamps_us(table[ts_col])
-    key_d, ts_d = col.to_dev(key), col.to_dev(ts)
+    (key_d,), n_keys, _ = encode_keys_dev([table], partition_cols)
+    ts_d, _ = timestamps_dev(table[ts_col])
     out, perm = None, None
     extra = {}
     for c in cols:

@@ -609,6 +609,50 @@ def key_counts(key, n_keys, stride=1):
     return counts
 
 
+_ARROW_KINDS = {"i32": (_lib.ARROW_I32, torch.int32), "i64": (_lib.ARROW_I64, torch.int64),
+                "f64": (_lib.ARROW_F64, torch.float64), "i64_raw": (_lib.ARROW_I64_RAW, torch.int64)}
+
+
+def arrow_import(arr, kind, device=None):
+    """A pyarrow Array or ChunkedArray to a device column through the Arrow C data interface: the
+    value buffers are copied from where Arrow holds them, chunk by chunk, into one device tensor.
+
+    kind: "i32" | "i64" (timestamps -> microseconds) | "i64_raw" (timestamps as stored) | "f64".
+    Dictionary arrays give their indices.  Returns (values, valid uint8 or None, null_count)."""
+    code, dtype = _ARROW_KINDS[kind]
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    chunks = arr.chunks if hasattr(arr, "chunks") else [arr]
+    n = sum(len(c) for c in chunks)
+    any_nulls = any(c.null_count for c in chunks)
+    out = torch.empty(n, dtype=dtype, device=dev)
+    valid = torch.empty(n, dtype=torch.uint8, device=dev) if any_nulls else None
+    total_nulls, at, exported = 0, 0, []
+    try:
+        for c in chunks:
+            m = len(c)
+            if m == 0:
+                continue
+            c_arr, c_sch = _lib.ArrowArray(), _lib.ArrowSchema()
+            c._export_to_c(C.addressof(c_arr), C.addressof(c_sch))
+            exported.append((c_arr, c_sch))
+            ws = _workspace(lib().tmp_arrow_import_workspace_bytes(C.byref(c_arr), C.byref(c_sch)), dev)
+            nulls = C.c_int64(0)
+            check(lib().tmp_arrow_import(C.byref(c_arr), C.byref(c_sch), code, out[at:].data_ptr(),
+                                         None if valid is None else valid[at:].data_ptr(), C.byref(nulls),
+                                         ws.data_ptr(), ws.numel(), _stream()), "tmp_arrow_import")
+            total_nulls += nulls.value
+            at += m
+    finally:
+        # the copies read the Arrow buffers: let the stream pass them before they are released
+        torch.cuda.current_stream().synchronize()
+        for c_arr, c_sch in exported:
+            if c_arr.release:
+                c_arr.release(C.byref(c_arr))
+            if c_sch.release:
+                c_sch.release(C.byref(c_sch))
+    return out, valid, total_nulls
+
+
 def write_layout(key, ts, n_keys):
     """Derived columns and row order of a date-partitioned, (key, time)-clustered table
     (python/tempo/io.py:29-39).
