@@ -124,6 +124,13 @@ struct RsShared {
   T mn0[RK_NSB], mx0[RK_NSB];
   T mn_pre[RK_NSB], mn_suf[RK_NSB], mx_pre[RK_NSB], mx_suf[RK_NSB];
   T gmn[RK_GLEVELS][64], gmx[RK_GLEVELS][64];
+  // the two halves of every sub-block on their own (sums of the first half are total - second):
+  // a frame's first and last sub-block are then walked slot by slot over at most half their slots
+  double hs2[RK_NSB], hq2[RK_NSB];           // second half: sum(x - pivot), sum((x - pivot)^2)
+  uint64_t hi2[kIntT ? RK_NSB : 1];          // ... exact integer sum
+  uint32_t hc2[RK_NSB];                      // ... counts (as bc)
+  T hmn1[RK_NSB], hmx1[RK_NSB], hmn2[RK_NSB], hmx2[RK_NSB];
+  int a_lead[RK_ROWS / 16];  // frame start (slot) of every 16th row of the tile
   int pivot_at;
   int nonfinite;  // some staged value is NaN or +-inf
 };
@@ -155,30 +162,44 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   const uint64_t base = comp[rs] >> low;
   if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; }
   __syncthreads();
+#ifdef RK_TIMING
+  long long tk[12]; int ntk = 0;
+#define RTICK() do { __syncthreads(); tk[ntk++] = clock64(); } while (0)
+#else
+#define RTICK() do {} while (0)
+#endif
+  RTICK();
 
   // ---- stage the region: one coalesced read of sort words and metric values
   constexpr int kPer = (RK_CAP + RK_THREADS - 1) / RK_THREADS;
   T xv[kPer];
   bool ok[kPer], fin[kPer];
+  uint64_t wd[kPer];
+  // all loads first, none inside a branch (a slot past the region reads the region's last row):
+  // loads inside per-slot branches are each waited for before the next is issued
+#pragma unroll
+  for (int r = 0; r < kPer; ++r) {
+    const int e = r * RK_THREADS + tid;
+    const int64_t at = rs + (e < len ? e : len - 1);
+    wd[r] = comp[at];
+    xv[r] = xs[at];
+  }
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     int e = r * RK_THREADS + tid;
     ok[r] = false;
     fin[r] = false;
-    xv[r] = MinMax<T>::null_slot();
     if (e < RK_CAP) {
       uint32_t c = RK_SAT << 1;  // past-the-end slots sort after everything
       if (e < len) {
-        uint64_t word = comp[rs + e];
+        const uint64_t word = wd[r];
         uint64_t rel = (word >> low) - base;
         ok[r] = (word & 1ull) != 0;
         c = (uint32_t)(rel < RK_SAT ? rel : RK_SAT) << 1 | (ok[r] ? 1u : 0u);
-        if (ok[r]) {
-          xv[r] = xs[rs + e];
-          fin[r] = Ord<T>::finite(xv[r]);
-          if (!fin[r]) s.nonfinite = 1;
-        }
+        fin[r] = ok[r] && Ord<T>::finite(xv[r]);
+        if (ok[r] && !fin[r]) s.nonfinite = 1;
       }
+      if (!ok[r]) xv[r] = MinMax<T>::null_slot();
       s.ck[e] = c;
       s.x[e] = xv[r];
       // pivot = first finite value of the region: one LDS atomic per wave, not per slot
@@ -187,17 +208,44 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
   }
   __syncthreads();
+  RTICK();
   const int pat = s.pivot_at;
   const double pivot = pat < RK_CAP ? (double)s.x[pat] : 0.0;
 
+  // first slot at or after the frame start of the row whose relative sort word is krel, searched
+  // in slots [lo, hi]; the row's full word is base + krel (rows with a saturated krel are deferred)
+  auto frame_first = [&](uint32_t krel, int lo, int hi) {
+    const uint64_t kstart = frame_start_key(base + krel, pmask, w);
+    const uint64_t srel64 = kstart > base ? kstart - base : 0;
+    const uint32_t srel = (uint32_t)(srel64 < RK_SAT ? srel64 : RK_SAT);
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((s.ck[mid] >> 1) < srel) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
   // ---- per 8-slot sub-block aggregates: one thread per sub-block adds its eight staged slots up
-  //      in registers (a few waves' worth of plain adds instead of cross-lane scans in every wave)
+  //      in registers (a few waves' worth of plain adds instead of cross-lane scans in every wave);
+  //      the next wave meanwhile searches the frame start of every 16th row over the whole
+  //      region -- frame starts are monotone, so the rows in between search only between two of these
+  if (wave == (RK_NSB + 63) / 64) {
+    const int64_t il = t0 + lane * 16;
+    if (il < t1) {
+      const int lil = (int)(il - rs);
+      s.a_lead[lane] = frame_first(s.ck[lil] >> 1, 0, lil);
+    }
+  }
   if (tid < RK_NSB) {
     const int b = tid;
     double sd = 0.0, sq = 0.0;
     uint32_t sc = 0;
     uint64_t si = 0;
     T vmn = MinMax<T>::min_identity(), vmx = MinMax<T>::max_identity();
+    double sd1 = 0.0, sq1 = 0.0;
+    uint32_t sc1 = 0;
+    uint64_t si1 = 0;
+    T vmn1 = vmn, vmx1 = vmx;
     uint32_t cs[RK_SB];
 #pragma unroll
     for (int q4 = 0; q4 < RK_SB / 4; ++q4) {
@@ -216,7 +264,17 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       vmn = MinMax<T>::mn(vmn, okj ? v : MinMax<T>::min_identity());
       vmx = MinMax<T>::mx(vmx, okj ? v : MinMax<T>::max_identity());
       if (kInt) si += okj ? (uint64_t)v : 0ull;
+      if (j == RK_SB / 2 - 1) {  // the first half is complete: keep it and start the second
+        sd1 = sd; sq1 = sq; sc1 = sc; si1 = si; vmn1 = vmn; vmx1 = vmx;
+        sd = 0.0; sq = 0.0; sc = 0; si = 0;
+        vmn = MinMax<T>::min_identity(); vmx = MinMax<T>::max_identity();
+      }
     }
+    s.hs2[b] = sd; s.hq2[b] = sq; s.hc2[b] = sc;
+    if (kInt) s.hi2[b] = si;
+    s.hmn1[b] = vmn1; s.hmx1[b] = vmx1; s.hmn2[b] = vmn; s.hmx2[b] = vmx;
+    sd += sd1; sq += sq1; sc += sc1; si += si1;
+    vmn = MinMax<T>::mn(vmn, vmn1); vmx = MinMax<T>::mx(vmx, vmx1);
     s.bs[b + 1] = sd;  // shifted by one: turned into exclusive prefixes below
     s.bq[b + 1] = sq;
     s.bc[b + 1] = sc;
@@ -225,6 +283,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     s.mx0[b] = vmx;
   }
   __syncthreads();
+  RTICK();
 
   // ---- wave 0: prefixes over the sub-blocks; waves 1 / 2: the sparse tables (wave-local work,
   //      LDS keeps one wave's accesses in order)
@@ -296,7 +355,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
   }
   __syncthreads();
-  // sparse table over the group extremes, in registers: wave 0 the minima, wave 1 the maxima
+  // sparse table over the group extremes, in registers: wave 0 the minima, wave 1 the maxima;
   if (wave < 2) {
     T v = lane < RK_NGRP ? (wave == 0 ? s.gmn[0][lane] : s.gmx[0][lane])
                          : (wave == 0 ? MinMax<T>::min_identity() : MinMax<T>::max_identity());
@@ -308,29 +367,26 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
   }
   __syncthreads();
+  RTICK();
 
   // ---- one output row per thread
   const int64_t i = t0 + tid;
+#ifndef RK_TIMING
   if (i >= t1) return;
+#endif
   const int li = (int)(i - rs);
   const uint32_t cki = s.ck[li];
-  const uint64_t k = comp[i] >> low;
-  const uint64_t kstart = frame_start_key(k, pmask, w);
   const uint32_t krel = cki >> 1;
-  const uint64_t srel64 = kstart > base ? kstart - base : 0;
-  const uint32_t srel = (uint32_t)(srel64 < RK_SAT ? srel64 : RK_SAT);
   int a, b;
   {
-    int lo = 0, hi = li;  // first slot in [0, li] at or after the frame start
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if ((s.ck[mid] >> 1) < srel) lo = mid + 1;
-      else hi = mid;
-    }
-    a = lo;
+    // first slot at or after the frame start: between the starts found for the 16th rows around
+    const int g = tid >> 4;
+    int hi = li;
+    if (g + 1 < RK_ROWS / 16 && t0 + (g + 1) * 16 < t1) hi = s.a_lead[g + 1] < li ? s.a_lead[g + 1] : li;
+    a = frame_first(krel, s.a_lead[g], hi);
     // last slot of the row's own second: gallop forward (usually the row itself or close)
     int step = 1;
-    lo = li + 1;
+    int lo = li + 1;
     hi = li + 1;
     while (hi < len && (s.ck[hi] >> 1) <= krel) { lo = hi + 1; hi += step; step <<= 1; }
     if (hi > len) hi = len;
@@ -341,6 +397,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
     b = lo - 1;
   }
+  RTICK();
   o.perm[i] = (int32_t)perm[i];
   const bool open_left = a == 0 && rs > 0;          // the frame may start before the region
   const bool open_right = b == len - 1 && re < n;   // peers may continue after the region
@@ -353,8 +410,13 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   T mn = MinMax<T>::min_identity(), mx = MinMax<T>::max_identity();
   const int sa = a / RK_SB, sb = b / RK_SB;
   if (!slow) {
-    const int head_end = sa == sb ? b : (sa + 1) * RK_SB - 1;
-    const int tail_begin = sa == sb ? b + 1 : sb * RK_SB;
+    // first and last sub-block: slot by slot up to the middle or the end of the sub-block,
+    // whichever comes first; the half beyond the middle comes from the half aggregates
+    constexpr int kHalf = RK_SB / 2;
+    const bool head_half = sa != sb && (a % RK_SB) < kHalf;   // head stops at the middle, + second half
+    const bool tail_half = sa != sb && (b % RK_SB) >= kHalf;  // first half + tail from the middle on
+    const int head_end = sa == sb ? b : (head_half ? sa * RK_SB + kHalf - 1 : (sa + 1) * RK_SB - 1);
+    const int tail_begin = sa == sb ? b + 1 : (tail_half ? sb * RK_SB + kHalf : sb * RK_SB);
     if constexpr (!kInt) {
       if (!s.nonfinite) {
       // every staged value is finite and NULL slots hold NaN: no per-slot tests needed
@@ -380,6 +442,23 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
         }
       }
     }
+    if (head_half) {
+      sd += s.hs2[sa];
+      sq += s.hq2[sa];
+      dc += s.hc2[sa];
+      if (kInt) isum += s.hi2[sa];
+      mn = MinMax<T>::mn(mn, s.hmn2[sa]);
+      mx = MinMax<T>::mx(mx, s.hmx2[sa]);
+    }
+    if (tail_half) {  // first half = whole sub-block - second half
+      sd += (s.bs[sb + 1] - s.bs[sb]) - s.hs2[sb];
+      sq += (s.bq[sb + 1] - s.bq[sb]) - s.hq2[sb];
+      dc += (s.bc[sb + 1] - s.bc[sb]) - s.hc2[sb];
+      if (kInt) isum += (s.bi[sb + 1] - s.bi[sb]) - s.hi2[sb];
+      mn = MinMax<T>::mn(mn, s.hmn1[sb]);
+      mx = MinMax<T>::mx(mx, s.hmx1[sb]);
+    }
+    RTICK();
     const int m0 = sa + 1, m1 = sb - 1;
     if (m0 <= m1) {
       sd += s.bs[m1 + 1] - s.bs[m0];
@@ -405,6 +484,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
     slow = (dc >> 16) != 0;  // a non-finite value inside the frame
   }
+  RTICK();
   // A frame that leaves the staged region (or a region too wide for 32-bit relative words) is
   // not evaluated here: the row is marked and the wide path completes it.
   const bool defer = open_left || open_right || krel >= RK_SAT;
@@ -459,6 +539,12 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     o.zscore[i] = z_ok ? ((double)s.x[li] - mean) * fast_rcp(stddev) : 0.0;
     o.valid[i] = (uint8_t)((okk ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
   }
+#ifdef RK_TIMING
+  RTICK();
+  if (tid == 0 && (blockIdx.x % 99991) == 777)
+    printf("R tile %d: stage %lld aggr %lld scans %lld search %lld headtail %lld middle %lld epilogue %lld\n", tile,
+           tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6]);
+#endif
 }
 
 struct RsPlan {
