@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per operator per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=48_000_000, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-shuffled", action="store_true",
                     help="skip the extra withRangeStats run on a row-permuted tick table")
@@ -463,8 +463,11 @@ def cpu_baseline(sample_rows):
     total = t2 - t0
     return dict(value=(nl + nr + sample_rows) / total, unit="rows/s", cores=threads, kind="port",
                 sample=("C oracle (oracle/tempo_oracle.c), %d threads over key shards: asofJoin %d+%d rows "
-                        "%.2f s, withRangeStats %d rows %.2f s; same distributions as the GPU workload"
-                        % (threads, nl, nr, t1 - t0, sample_rows, t2 - t1)))
+                        "%.2f s, withRangeStats %d rows %.2f s; same distributions as the GPU workload, "
+                        "1/%d of its rows per operator (bounded so that the default run stays within minutes; "
+                        "the oracle's union + sort plan holds about 100 bytes per row on the host, "
+                        "so the full 10^9 rows per operator would need about 100 GB of host memory)"
+                        % (threads, nl, nr, t1 - t0, sample_rows, t2 - t1, max(1, 1_000_000_000 // max(sample_rows, 1)))))
 
 
 if __name__ == "__main__":

@@ -590,6 +590,13 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     uint64_t pay[(PAY && !POS) ? NP : 1][(PAY && !POS) ? RS_ITEMS : 1];
     uint32_t rank[RS_ITEMS];
     uint32_t cnt_inc = 0;
+#ifdef RS_TIMING
+    long long tk[12]; int ntk = 0;
+#define STICK() do { __syncthreads(); tk[ntk++] = clock64(); } while (0)
+#else
+#define STICK() do {} while (0)
+#endif
+    STICK();
     if (PREFETCH) {
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
@@ -613,6 +620,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         k[it] = pos < tile_n ? kin[tile_base + pos] : 0ull;
       }
     }
+    STICK();
     if (PAY && !POS) {
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
@@ -649,6 +657,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       rank[it] = prior + (uint32_t)__popcll(peers & lt_mask);
     }
     __syncthreads();
+    STICK();
     // digit `tid` (first 256 threads): exclusive prefix of its count over the waves, then over
     // the digits
     uint32_t cnt_d = 0;
@@ -673,6 +682,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       dstart[tid] = wp + cnt_inc - cnt_d;
     }
     __syncthreads();
+    STICK();
     // words: to their place in the tile's digit order, then out in runs
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
@@ -684,6 +694,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
       }
     }
     __syncthreads();
+    STICK();
     uint32_t gpos[RS_ITEMS];  // global position of the tile slot tid + j * RS_THREADS
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
@@ -702,6 +713,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (p < tile_n) vout[gpos[j]] = (uint32_t)(sbuf[p] & id_mask);
       }
     }
+    STICK();
     if (PACK == 0) {
       __syncthreads();
       // row ids through the same buffer (read only now unless the payload needed them: fewer
@@ -723,6 +735,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         if (p < tile_n) vout[gpos[j]] = sbuf32[p];
       }
     }
+    STICK();
     if (PAY && !POS) {
 #pragma unroll
       for (int c = 0; c < NP; ++c) {
@@ -772,6 +785,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     __syncthreads();
     if (tid < RS_RADIX) goff[tid] += cnt_d;
     __syncthreads();
+#ifdef RS_TIMING
+    STICK();
+    if (tid == 0 && t == 1 && (blockIdx.x % 300) == 7)
+      printf("X npay %d bits %d first %d pack %d: load %lld rank %lld scan %lld lds %lld outw %lld ids %lld pay %lld\n", NPAY, RS_BITS,
+             (int)FIRST, PACK, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6]);
+#endif
   }
 }
 
@@ -1512,10 +1531,31 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint64_t *win, cons
       }
       wout[s + j] = w;
       idout[s + j] = id;
-      const uint64_t from = pp.positional ? (uint64_t)(s + (int64_t)(pk & idx_mask)) : (uint64_t)id;
+      if (!pp.positional) {
 #pragma unroll
-      for (int c = 0; c < kMaxPay; ++c)
-        if (c < pp.n) pp.out[c][s + j] = pp.src[c][from];
+        for (int c = 0; c < kMaxPay; ++c)
+          if (c < pp.n) pp.out[c][s + j] = pp.src[c][id];
+      }
+    }
+  }
+  if (pp.positional) {
+    // payload that travelled with the pairs: each column is read as it lies (coalesced) into the
+    // tile buffer and leaves in sorted order from there, instead of one 8-byte fetch per row
+    // from wherever its slot was
+#pragma unroll 1
+    for (int c = 0; c < pp.n; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = tid + it * NT;
+        if (j < m) sbuf[j] = pp.src[c][s + j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const int j = tid + it * NT;
+        if (j < m) pp.out[c][s + j] = sbuf[(uint32_t)(wv[it] & idx_mask)];
+      }
     }
   }
   TICK();
