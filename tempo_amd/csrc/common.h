@@ -116,6 +116,11 @@ struct RangeInfo {
   // end to end (what a rank holds after the key shuffle) has few of them.  n_desc counts them while
   // it is <= kMaxDesc; desc_pos holds the first kMaxDesc positions found, in no particular order.
   int32_t n_desc;
+  // windows of consecutive rows, looked at key by key: pairs of successive rows of one key seen,
+  // and how many of them step back in (primary, seq).  Many pairs and no step back: every key's
+  // rows are probably in order already (a feed of interleaved devices whose clocks are not aligned).
+  int32_t key_pairs;
+  int32_t key_viol;
   int32_t pad_;
   int64_t desc_pos[15];
 };
@@ -189,10 +194,14 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
                 const uint64_t *const *pay_src = nullptr, uint64_t *const *pay_out = nullptr,
                 bool *carried = nullptr);
 // 3 = a few time-ordered runs end to end: merged by time first, then as 2.
+// 4 = every key's rows look ordered (sampled): the passes over the key bits are tried on their own
+//     and the result is checked; the full sort stands by.
+constexpr int kKeyPairsEvidence = 4096;
 inline int sorted_mode(const RangeInfo &r) {
   if (!r.unsorted) return 1;
   if (!r.time_unsorted) return 2;
-  return (r.n_desc >= 1 && r.n_desc <= kMaxDesc) ? 3 : 0;
+  if (r.n_desc >= 1 && r.n_desc <= kMaxDesc) return 3;
+  return (r.key_pairs >= kKeyPairsEvidence && r.key_viol == 0) ? 4 : 0;
 }
 int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, OrderResult *res,
                        hipStream_t st, int n_pay = 0, const uint64_t *const *pay_src = nullptr,

@@ -51,6 +51,8 @@ __global__ void range_init_kernel(RangeInfo *r) {
   r->not_thousands = 0;
   r->not_millions = 0;
   r->n_desc = 0;
+  r->key_pairs = 0;
+  r->key_viol = 0;
   r->pad_ = 0;
   for (int i = 0; i < kMaxDesc; ++i) r->desc_pos[i] = 0;
 }
@@ -1650,12 +1652,102 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, int c
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Is every key's own row sequence in order?  A sample: kKoWindows windows of kKoRows consecutive
+// rows each, one wave per window.  The wave walks its window 64 rows at a time and keeps, per key
+// seen so far, the (primary, seq) of that key's latest row in a small LDS hash table; every row
+// that has a predecessor of its key inside the window is one pair, a pair that steps back one
+// violation.  The result only steers which ordering is tried first -- it proves nothing.
+// ------------------------------------------------------------------------------------------
+constexpr int kKoWindows = 512;
+constexpr int kKoRows = 1024;
+constexpr int kKoSlots = 2048;
+constexpr int64_t kKoMinRows = 1 << 20;  // smaller tables: not worth a look
+
+__global__ __launch_bounds__(64) void key_order_sample_kernel(int64_t n, const int32_t *key, const int64_t *ts,
+                                                              int64_t div, const int64_t *seq, const uint8_t *seq_valid,
+                                                              RangeInfo *out) {
+  __shared__ uint32_t tkey[kKoSlots];
+  __shared__ int64_t tprim[kKoSlots], tseq[kKoSlots];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < kKoSlots; i += 64) tkey[i] = 0xffffffffu;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int64_t start = (int64_t)blockIdx.x * (n / kKoWindows);
+  if (start + kKoRows > n) start = n - kKoRows;
+  int pairs = 0, viol = 0;
+  for (int bt = 0; bt < kKoRows / 64; ++bt) {
+    const int64_t i = start + bt * 64 + lane;
+    const uint32_t k = (uint32_t)key[i];
+    const int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
+    // NULL sequence values sort first: below every real one
+    const bool sv = seq && (!seq_valid || seq_valid[i]);
+    const int64_t q = seq ? (sv ? seq[i] : INT64_MIN) : 0;
+    // lanes of this step with my key
+    uint64_t peers = ~0ull;
+    for (int b = 0; b < 32; ++b) {
+      const bool bit = (k >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const uint64_t before = peers & lt_mask;
+    bool have = false;
+    int64_t pp = 0, pq = 0;
+    const int prev = before ? 63 - __clzll((long long)before) : lane;
+    const int64_t sp = __shfl(p, prev, 64), sq = __shfl(q, prev, 64);
+    uint32_t h = (k * 2654435761u) >> 21;  // 11 bits
+    if (before) {
+      have = true; pp = sp; pq = sq;
+    } else {
+      for (int probe = 0; probe < kKoSlots; ++probe) {
+        const uint32_t kk = tkey[h];
+        if (kk == k) { have = true; pp = tprim[h]; pq = tseq[h]; break; }
+        if (kk == 0xffffffffu) break;
+        h = (h + 1) & (kKoSlots - 1);
+      }
+    }
+    if (have) {
+      ++pairs;
+      if (p < pp || (p == pp && q < pq)) ++viol;
+    }
+    // the key's last lane of this step leaves its values for the steps to come (keys of one step
+    // are distinct among these lanes; the window holds fewer rows than the table has slots)
+    if (!(peers & ~lt_mask & ~(1ull << lane))) {
+      h = (k * 2654435761u) >> 21;
+      for (int probe = 0; probe < kKoSlots; ++probe) {
+        const uint32_t old = atomicCAS(&tkey[h], 0xffffffffu, k);
+        if (old == 0xffffffffu || old == k) { tprim[h] = p; tseq[h] = q; break; }
+        h = (h + 1) & (kKoSlots - 1);
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    pairs += __shfl_xor(pairs, o, 64);
+    viol += __shfl_xor(viol, o, 64);
+  }
+  if (lane == 0) {
+    if (pairs) atomicAdd(&out->key_pairs, pairs);
+    if (viol) atomicAdd(&out->key_viol, viol);
+  }
+}
+
+// Raises *flag when the words are not in order (compared above their low bits).
+__global__ __launch_bounds__(kBlock) void ordered_check_kernel(const uint64_t *w, int64_t n, int low_bits, int32_t *flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
+    bad |= (w[i] >> low_bits) < (w[i - 1] >> low_bits);
+  if (__any(bad) && (threadIdx.x & 63) == 0 && __atomic_load_n(flag, __ATOMIC_RELAXED) == 0) atomicOr(flag, 1);
+}
+
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
   TMP_LAUNCH(range_init_kernel, dim3(1), dim3(1), st, b.range);
   if (s.n > 0) {
     int grid = grid_for(s.n, kBlock * 16, 4096);
     TMP_LAUNCH(range_scan_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts,
                        s.prim_div, s.seq, s.seq_valid, b.range);
+    if (s.key && s.n >= kKoMinRows && !getenv("TEMPO_NO_KEY_ORDER"))
+      TMP_LAUNCH(key_order_sample_kernel, dim3(kKoWindows), dim3(64), st, s.n, s.key, s.ts, s.prim_div, s.seq,
+                 s.seq_valid, b.range);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
@@ -1934,6 +2026,33 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     }
     return radix_passes(b, s.n, lay.key_shift(), hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr, nullptr,
                         nullptr, 1);
+  }
+  if (sorted == 4) {
+    // every key's rows look ordered: stable passes over the key bits alone, as for a time-ordered
+    // feed, then a check of the result; the full sort stands by behind the check's flag
+    const int key_passes = passes_for(hi_bit - lay.key_shift());
+    if (lay.key_bits > 0 && !lay.seq_wide && b.fallback && !b.run_if &&
+        passes_for(hi_bit - lay.low_bits) >= key_passes + 1) {
+      TMP_CHECK_HIP(hipMemsetAsync(b.fallback, 0, sizeof(int32_t), st));
+      OrderResult quick;
+      TMP_TRY(radix_passes(b, s.n, lay.key_shift(), hi_bit, &quick, st, n_pay, pay_src, pay_out, carried, &gen));
+      TMP_LAUNCH(ordered_check_kernel, dim3(grid_for(s.n, kBlock * 8, 8192)), dim3(kBlock), st, quick.comp, s.n,
+                 lay.low_bits, b.fallback);
+      b.run_if = b.fallback;
+      OrderResult plain;
+      int rc = radix_passes(b, s.n, lay.low_bits, hi_bit, &plain, st, n_pay, pay_src, pay_out, nullptr, &gen);
+      if (rc == TMP_OK && plain.comp != quick.comp) {
+        const int at = quick.comp == b.comp[0] ? 0 : 1;
+        TMP_LAUNCH(copy_pairs_if_kernel, dim3(grid_for(s.n, kBlock * 4, 8192)), dim3(kBlock), st, plain.comp, plain.perm,
+                   b.comp[at], b.idx[at], s.n, b.run_if);
+      }
+      b.run_if = nullptr;
+      TMP_TRY(rc);
+      TMP_CHECK_HIP(hipGetLastError());
+      *res = quick;
+      return TMP_OK;
+    }
+    sorted = 0;
   }
   if (lay.seq_wide && s.seq && sorted == 0) {
     // the sequence values first (stable passes over words that hold nothing else), then the sort

@@ -158,3 +158,47 @@ def test_time_ordered_runs_with_sequence_and_operators(orc, monkeypatch):
     ref = orc.range_stats(key, ts, x, xv, 30)
     assert np.array_equal(out["perm"].cpu().numpy(), ref["perm"]) and np.array_equal(out["count"].cpu().numpy(), ref["count"])
     np.testing.assert_allclose(out["mean"].cpu().numpy(), ref["mean"], rtol=1e-9, atol=1e-12)
+
+
+def _per_key_ordered(rng, n, n_keys, jitter_us):
+    """Interleaved devices, each in its own time order, clocks not aligned: rows are not in time
+    order, yet every key's rows are."""
+    per = n // n_keys
+    n = per * n_keys
+    slot = np.repeat(np.arange(per, dtype=np.int64), n_keys)
+    key = np.tile(np.arange(n_keys, dtype=np.int32), per)
+    ts = BASE + slot * 1_000_000 + rng.integers(-jitter_us, jitter_us + 1, n)
+    return key, ts
+
+
+@pytest.mark.parametrize("floor_seconds", [False, True])
+def test_rows_ordered_within_every_key(orc, monkeypatch, floor_seconds):
+    """Large enough for the sampled look (2^20 rows): the key passes are tried on their own, the
+    check passes and no other sort kernel does any work."""
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(21)
+    key, ts = _per_key_ordered(rng, 1_300_000, 9, 200_000)
+    assert (np.diff(ts) < 0).sum() > 1000            # far more steps back than a handful of runs
+    names = _check(orc, key, ts, 9, floor_seconds=floor_seconds)
+    assert "ordered_check_kernel" in names and "tile_sort_kernel" not in names
+
+
+def test_key_order_guess_wrong_falls_back(orc, monkeypatch):
+    """The sampled windows see ordered keys, but one key has a single row out of place far from any
+    window's reach of its predecessor: the check fails and the stand-by full sort delivers."""
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(22)
+    key, ts = _per_key_ordered(rng, 1_300_000, 9, 200_000)
+    n = len(ts)
+    pos = 256 * (n // 512) + 2000                     # between two sampled windows (1024 rows every n / 512)
+    pos += (4 - pos) % 9
+    ts[pos] = ts[4]                                   # one row of key 4 jumps back to the start
+    names = _check(orc, key, ts, 9)
+    assert "ordered_check_kernel" in names
+    # ... and EMA / range stats on such a table equal the oracle's
+    from tempo_amd import ops
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = rng.normal(0, 1, n)
+    perm, ema = ops.ema(d(key), d(ts), d(x), None, 9, window=5, exp_factor=0.3)
+    operm, oema = orc.ema(key, ts, x, None, 5, 0.3)
+    assert np.array_equal(perm.cpu().numpy(), operm) and np.array_equal(ema.cpu().numpy(), oema)
