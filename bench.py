@@ -142,6 +142,8 @@ KERNEL_BYTES_PER_ROW = {
     "radix_scatter_kernel+carried": 40.0,
     "tile_bounds_kernel": 8.0,
     "key_sample_kernel": 0.25,
+    "tile_merge_kernel": 24.0,        # key 4 + ts 8 (+ mask bytes) in, word 8 + row id 4 out
+    "ordered_check_kernel": 8.0,
     "lastnn_scan_kernel<false>": 16.0,       # word 8 in, 2 x 4 B out
     "lastnn_reduce_kernel<false>": 8.0,
     "range_scan_kernel": 12.0,        # key 4 + ts 8 in
