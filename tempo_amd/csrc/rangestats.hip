@@ -20,7 +20,10 @@
 namespace tmp {
 
 constexpr int RK_ROWS = 1024;
-constexpr int RK_CAP = 2560;
+#ifndef TEMPO_RK_CAP
+#define TEMPO_RK_CAP 2560
+#endif
+constexpr int RK_CAP = TEMPO_RK_CAP;
 constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
 #ifndef TEMPO_RK_WPS
