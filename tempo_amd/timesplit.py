@@ -25,6 +25,8 @@ global input order when the ranks' inputs are consecutive chunks of the global t
 arrive ordered by source rank, then source position).
 
 Context rows produce no output of their own: the results of a rank are those of its owned rows.
+With hot_keys=[...] only those keys are cut along the time axis; the rows of every other key go,
+whole, to the key's hash owner in the same exchange (a table with a Zipf head and a long tail).
 The tails exchanged are n_keys x halo rows per rank, which is what makes this the path for one
 series or a few hot ones and not for a million keys (those hash).
 
@@ -147,6 +149,39 @@ def _owner(ts, cuts):
     return torch.bucketize(ts, cuts.to(ts.device), right=True)
 
 
+class _Routing:
+    """Which rows go by time range and which by key.  hot_keys=None: every key is cut along the
+    time axis.  Otherwise only the listed key ids are; the rows of every other key go, whole, to
+    cold_owner[key] (default: the hash owner, tmp_key_owner) and need no context from elsewhere."""
+
+    def __init__(self, world, n_keys, hot_keys, cold_owner, dev):
+        self.all_hot = hot_keys is None
+        if self.all_hot:
+            return
+        hot = torch.zeros(n_keys, dtype=torch.bool)
+        hot[torch.as_tensor(list(hot_keys), dtype=torch.int64)] = True
+        if cold_owner is None:
+            from . import _lib
+            cold_owner = torch.tensor([_lib.lib().tmp_key_owner(k, world) for k in range(n_keys)], dtype=torch.int64)
+        self.hot = hot.to(dev)
+        self.cold_owner = torch.as_tensor(cold_owner).to(torch.int64).to(dev)
+
+    def is_hot(self, key):
+        if self.all_hot:
+            return torch.ones(key.shape[0], dtype=torch.bool, device=key.device)
+        return self.hot[key.long()]
+
+    def owner(self, key, ts, cuts):
+        o = _owner(ts, cuts)
+        if self.all_hot:
+            return o
+        k = key.long()
+        return torch.where(self.hot[k], o, self.cold_owner[k])
+
+    def sample_of(self, key, ts):
+        return ts if self.all_hot else ts[self.hot[key.long()]]
+
+
 def _filled(t, n, dev, dtype, value):
     return torch.full((n,), value, dtype=dtype, device=dev) if t is None else t
 
@@ -221,10 +256,12 @@ def _prep(t, n_keys):
     return key, ts, n, dev
 
 
-def range_stats_by_time(comm, tables, n_keys, range_back_secs, ts_is_seconds=False, local_ops=None):
+def range_stats_by_time(comm, tables, n_keys, range_back_secs, ts_is_seconds=False, local_ops=None,
+                        hot_keys=None, cold_owner=None):
     """withRangeStats over time ranges.  tables: per rank this process plays, dict(ts=, x=,
     key=None, x_valid=None, extra=[columns to pass through]).  Returns per rank the statistics of
-    its owned rows in (key, second) order, with key, ts and the extra columns alongside."""
+    its owned rows in (key, second) order, with key, ts and the extra columns alongside.
+    hot_keys / cold_owner: see _Routing (only the hot keys are cut along time, the rest hash)."""
     lops = local_ops or ops
     world = comm.world
     unit = 1 if ts_is_seconds else 1_000_000
@@ -235,8 +272,10 @@ def range_stats_by_time(comm, tables, n_keys, range_back_secs, ts_is_seconds=Fal
         key, ts, n, dev = _prep(t, n_keys)
         x_valid = _filled(t.get("x_valid"), n, dev, torch.uint8, 1)
         tab = _Table(key=key, ts=ts, x=t["x"], x_valid=x_valid, **_extras(t))
-        cuts = yield from _cuts(world, [ts], unit)
-        own = _owner(ts, cuts)
+        route = _Routing(world, n_keys, hot_keys, cold_owner, dev)
+        cuts = yield from _cuts(world, [route.sample_of(key, ts)], unit)
+        own = route.owner(key, ts, cuts)
+        hot = route.is_hot(key)
         cl = cuts.tolist()
         # rank r needs the rows from second(start of its range) - W on; which lower ranks can hold
         # such rows follows from the cuts alone, so every rank loops over the same distances
@@ -251,7 +290,7 @@ def range_stats_by_time(comm, tables, n_keys, range_back_secs, ts_is_seconds=Fal
         dests, sels = [own], []
         for d in range(1, d_max + 1):
             r = own + d
-            idx = ((r < world) & (ts >= need_d[r.clamp(max=world - 1)])).nonzero().squeeze(1)
+            idx = (hot & (r < world) & (ts >= need_d[r.clamp(max=world - 1)])).nonzero().squeeze(1)
             dests.append(r[idx])
             sels.append(idx)
         n_ctx = sum(i.numel() for i in sels)
@@ -272,7 +311,7 @@ def range_stats_by_time(comm, tables, n_keys, range_back_secs, ts_is_seconds=Fal
     return _drive(comm, body)
 
 
-def _row_halo(comm, tables, n_keys, halo, ts_is_seconds, lops, col_names, run_local):
+def _row_halo(comm, tables, n_keys, halo, ts_is_seconds, lops, col_names, run_local, hot_keys=None, cold_owner=None):
     """Common part of EMA and lookback: owned rows by time range, then per key the last `halo`
     rows from the ranges below.  run_local(table, n_carry) computes the rank's result."""
     world = comm.world
@@ -284,12 +323,15 @@ def _row_halo(comm, tables, n_keys, halo, ts_is_seconds, lops, col_names, run_lo
         key, ts, n, dev = _prep(t, n_keys)
         named = {nm: t.get(nm) for nm in col_names}
         tab = _Table(key=key, ts=ts, seq=t.get("seq"), seq_valid=t.get("seq_valid"), **named, **_extras(t))
-        cuts = yield from _cuts(world, [ts], unit)
-        got = yield ("exchange", _owner(ts, cuts).to(torch.int32), tab.cols)
+        route = _Routing(world, n_keys, hot_keys, cold_owner, dev)
+        cuts = yield from _cuts(world, [route.sample_of(key, ts)], unit)
+        got = yield ("exchange", route.owner(key, ts, cuts).to(torch.int32), tab.cols)
         mine = tab.like(got)
         order = lambda tb, h: _tails(lops, tb.get("key"), tb.get("ts"), tb.get("seq"), tb.get("seq_valid"), n_keys, h,
                                      not ts_is_seconds)
-        everyone = yield ("gather", mine.take(order(mine, halo)).cols)
+        offer = order(mine, halo)
+        offer = offer[route.is_hot(mine.get("key")[offer])]  # keys that hash are whole where they are
+        everyone = yield ("gather", mine.take(offer).cols)
         lower = tab.like(_carry(rank, everyone))
         carry = lower.take(order(lower, halo))
         n_carry = carry.cols[0].shape[0]
@@ -299,7 +341,8 @@ def _row_halo(comm, tables, n_keys, halo, ts_is_seconds, lops, col_names, run_lo
     return _drive(comm, body)
 
 
-def ema_by_time(comm, tables, n_keys, window=30, exp_factor=0.2, ts_is_seconds=False, local_ops=None):
+def ema_by_time(comm, tables, n_keys, window=30, exp_factor=0.2, ts_is_seconds=False, local_ops=None,
+                hot_keys=None, cold_owner=None):
     """EMA over time ranges.  tables: dict(ts=, x=, key=None, x_valid=None, seq=None,
     seq_valid=None, extra=[]) per rank.  Returns per rank dict(key, ts, ema, extra) of its owned
     rows in window order."""
@@ -314,10 +357,12 @@ def ema_by_time(comm, tables, n_keys, window=30, exp_factor=0.2, ts_is_seconds=F
         return dict(key=kept.get("key"), ts=kept.get("ts"), ema=out[keep],
                     extra=[kept.get(nm) for nm in kept.names if nm.startswith("extra")])
 
-    return _row_halo(comm, tables, n_keys, window - 1, ts_is_seconds, lops, ["x", "x_valid"], run_local)
+    return _row_halo(comm, tables, n_keys, window - 1, ts_is_seconds, lops, ["x", "x_valid"], run_local, hot_keys,
+                     cold_owner)
 
 
-def lookback_by_time(comm, tables, n_keys, lookback_size, exact_size=True, ts_is_seconds=False, local_ops=None):
+def lookback_by_time(comm, tables, n_keys, lookback_size, exact_size=True, ts_is_seconds=False, local_ops=None,
+                     hot_keys=None, cold_owner=None):
     """withLookbackFeatures over time ranges.  tables: dict(ts=, xs=[feature columns], key=None,
     xs_valid=[... or None], seq=None, seq_valid=None, extra=[]) per rank.  Returns per rank
     dict(key, ts, lengths, feat, feat_valid, extra) of its owned rows that are kept."""
@@ -343,10 +388,10 @@ def lookback_by_time(comm, tables, n_keys, lookback_size, exact_size=True, ts_is
                     feat=feat[keep], feat_valid=None if fv is None else fv[keep],
                     extra=[kept.get(nm) for nm in kept.names if nm.startswith("extra")])
 
-    return _row_halo(comm, flat, n_keys, lookback_size, ts_is_seconds, lops, names, run_local)
+    return _row_halo(comm, flat, n_keys, lookback_size, ts_is_seconds, lops, names, run_local, hot_keys, cold_owner)
 
 
-def asof_join_by_time(comm, lefts, rights, n_keys, skip_nulls=True, local_ops=None):
+def asof_join_by_time(comm, lefts, rights, n_keys, skip_nulls=True, local_ops=None, hot_keys=None, cold_owner=None):
     """The plain AS-OF join over time ranges.  lefts: dict(ts=, key=None, cols=[8-byte columns])
     per rank; rights: dict(ts=, key=None, cols=[...], masks=[validity or None per column],
     seq=None, seq_valid=None).  Returns per rank what ops.asof_join_table returns for its left
@@ -367,16 +412,19 @@ def asof_join_by_time(comm, lefts, rights, n_keys, skip_nulls=True, local_ops=No
         right = _Table(key=kr, ts=tr, seq=rt.get("seq"), seq_valid=rt.get("seq_valid"),
                        **{"c%d" % i: c for i, c in enumerate(rt["cols"])},
                        **{nm: masks[i] for i, nm in enumerate(mask_name) if nm == "m%d" % i})
-        cuts = yield from _cuts(world, [tl, tr], 1)
-        got_l = yield ("exchange", _owner(tl, cuts).to(torch.int32), left.cols)
-        got_r = yield ("exchange", _owner(tr, cuts).to(torch.int32), right.cols)
+        route = _Routing(world, n_keys, hot_keys, cold_owner, tl.device)
+        cuts = yield from _cuts(world, [route.sample_of(kl, tl), route.sample_of(kr, tr)], 1)
+        got_l = yield ("exchange", route.owner(kl, tl, cuts).to(torch.int32), left.cols)
+        got_r = yield ("exchange", route.owner(kr, tr, cuts).to(torch.int32), right.cols)
         left, mine = left.like(got_l), right.like(got_r)
 
         def last(tb):
             ms = [tb.get(nm) for nm in sorted(set(n_ for n_ in mask_name if n_))] if skip_nulls else []
             return _last_rows(lops, tb.get("key"), tb.get("ts"), tb.get("seq"), tb.get("seq_valid"), n_keys, ms)
 
-        everyone = yield ("gather", mine.take(last(mine)).cols)
+        offer = last(mine)
+        offer = offer[route.is_hot(mine.get("key")[offer])]  # keys that hash are whole where they are
+        everyone = yield ("gather", mine.take(offer).cols)
         lower = right.like(_carry(rank, everyone))
         carry = lower.take(last(lower))
         full = right.like([torch.cat([a, b]) for a, b in zip(carry.cols, mine.cols)])

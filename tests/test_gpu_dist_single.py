@@ -311,3 +311,21 @@ def test_time_ranges_single_rank_nccl(orc):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_hot_key_by_time_rest_by_hash_on_the_device(orc, monkeypatch):
+    """One key holds half the rows and is cut along the time axis over 8 simulated ranks, the other
+    keys go to their hash owners in the same exchange; HIP routing and operators throughout."""
+    import timesplit_cases as tc
+    from tempo_amd import ops, timesplit
+    monkeypatch.setattr(tc, "HOT_SHARE", 0.5)
+    comm = timesplit.SimComm(8)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    kw = dict(hot_keys=[0])
+    have, want = tc.check_range_stats(comm, ops, T, n=90_000, n_keys=40, window=30, **kw)
+    assert have.keys() == want.keys()
+    tc.compare_range_stats(have, want)
+    have, want = tc.check_ema(comm, ops, T, n=80_000, n_keys=40, window=12, **kw)
+    assert have == want
+    have, want = tc.check_join(comm, ops, T, n=80_000, n_keys=40, **kw)
+    assert have == want

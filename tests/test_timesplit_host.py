@@ -56,3 +56,29 @@ def test_cuts_are_whole_seconds_and_shared():
     cuts = timesplit._drive(comm, body)
     assert all(torch.equal(c, cuts[0]) for c in cuts)
     assert (cuts[0] % 1_000_000 == 0).all() and (cuts[0][1:] >= cuts[0][:-1]).all()
+
+
+def test_hot_key_by_time_and_the_rest_by_hash(orc, monkeypatch):
+    """A key with 60 % of the rows is cut along the time axis, the other 19 keys hash to their
+    owners in the same exchange: every operator's union over the ranks is still the whole result,
+    and the hot key's rows really are spread (no rank holds more than half of them)."""
+    monkeypatch.setattr(tc, "HOT_SHARE", 0.6)
+    world, n_keys, kw = 4, 20, dict(hot_keys=[0])
+    have, want = tc.check_range_stats(_comm(world), oracle_ops, T, n=4000, n_keys=n_keys, window=25, **kw)
+    assert have.keys() == want.keys()
+    tc.compare_range_stats(have, want)
+    have, want = tc.check_ema(_comm(world), oracle_ops, T, n=3000, n_keys=n_keys, window=9, **kw)
+    assert have == want
+    have, want = tc.check_lookback(_comm(world), oracle_ops, T, n=2500, n_keys=n_keys, size=4, exact=False, **kw)
+    tc.compare_lookback(have, want)
+    have, want = tc.check_join(_comm(world), oracle_ops, T, n=3000, n_keys=n_keys, **kw)
+    assert have == want
+    # where the rows went
+    s = tc.make_series(2, 3000, n_keys)
+    tables = [dict(key=T(s["key"][sl]), ts=T(s["ts"][sl]), x=T(s["x"][sl]), x_valid=T(s["xv"][sl]), extra=[])
+              for sl in tc.chunks(3000, world)]
+    got = timesplit.ema_by_time(_comm(world), tables, n_keys, 9, 0.3, local_ops=oracle_ops, hot_keys=[0])
+    hot_rows = [int((g["key"] == 0).sum()) for g in got]
+    assert max(hot_rows) < 0.5 * sum(hot_rows) and min(hot_rows) > 0
+    for k in range(1, n_keys):
+        assert sum(int((g["key"] == k).any()) for g in got) <= 1, "a key that hashes landed on two ranks"

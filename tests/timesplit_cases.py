@@ -9,9 +9,14 @@ from tempo_amd import timesplit
 BASE = 1_596_240_000_000_000
 
 
+HOT_SHARE = 0.0   # > 0: key 0 holds that share of the rows (a hot key next to a tail of small ones)
+
+
 def make_series(seed, n, n_keys, span_s=900):
     rng = np.random.default_rng(seed)
     key = rng.integers(0, n_keys, n).astype(np.int32)
+    if HOT_SHARE:
+        key = np.where(rng.random(n) < HOT_SHARE, 0, key).astype(np.int32)
     ts = BASE + rng.integers(0, span_s * 1000, n) * 1000           # milliseconds: many rows per second
     x = rng.normal(50, 5, n)
     xv = (rng.random(n) > 0.15).astype(np.uint8)
@@ -29,14 +34,14 @@ def _by_rid(rid, *cols):
     return [np.asarray(c)[o] for c in cols]
 
 
-def check_range_stats(comm, lops, T, n=6000, n_keys=1, window=20, seed=1):
+def check_range_stats(comm, lops, T, n=6000, n_keys=1, window=20, seed=1, **kw):
     """T(array) -> tensor where the operator wants it.  comm.local names the ranks played here;
     returns {rid: (count, mean, max, valid)} for them and the expected dict for all rows."""
     s = make_series(seed, n, n_keys)
     use_key = n_keys > 1
     tables = [dict(key=T(s["key"][sl]) if use_key else None, ts=T(s["ts"][sl]), x=T(s["x"][sl]), x_valid=T(s["xv"][sl]),
                    extra=[T(s["rid"][sl])]) for sl in [chunks(n, comm.world)[r] for r in comm.local]]
-    got = timesplit.range_stats_by_time(comm, tables, n_keys, window, local_ops=lops)
+    got = timesplit.range_stats_by_time(comm, tables, n_keys, window, local_ops=lops, **kw)
     ref = lops.range_stats(T(s["key"]) if use_key else T(np.zeros(n, np.int32)), T(s["ts"]), T(s["x"]), T(s["xv"]),
                            n_keys, window)
     rp = ref["perm"].cpu().numpy()
@@ -60,13 +65,13 @@ def compare_range_stats(have, want):
             assert mx == wmx and abs(m - wm) <= 1e-9 * max(1.0, abs(wm)), (r, m, wm)
 
 
-def check_ema(comm, lops, T, n=5000, n_keys=1, window=7, seed=2, with_seq=False):
+def check_ema(comm, lops, T, n=5000, n_keys=1, window=7, seed=2, with_seq=False, **kw):
     s = make_series(seed, n, n_keys)
     use_key = n_keys > 1
     sq = lambda sl: dict(seq=T(s["seq"][sl]), seq_valid=T(s["sv"][sl])) if with_seq else {}
     tables = [dict(key=T(s["key"][sl]) if use_key else None, ts=T(s["ts"][sl]), x=T(s["x"][sl]), x_valid=T(s["xv"][sl]),
                    extra=[T(s["rid"][sl])], **sq(sl)) for sl in [chunks(n, comm.world)[r] for r in comm.local]]
-    got = timesplit.ema_by_time(comm, tables, n_keys, window, 0.3, local_ops=lops)
+    got = timesplit.ema_by_time(comm, tables, n_keys, window, 0.3, local_ops=lops, **kw)
     full = slice(0, n)
     perm, ref = lops.ema(T(s["key"]) if use_key else T(np.zeros(n, np.int32)), T(s["ts"]), T(s["x"]), T(s["xv"]), n_keys,
                          window, 0.3, **sq(full))
@@ -79,14 +84,14 @@ def check_ema(comm, lops, T, n=5000, n_keys=1, window=7, seed=2, with_seq=False)
     return have, want
 
 
-def check_lookback(comm, lops, T, n=4000, n_keys=1, size=5, seed=3, exact=True):
+def check_lookback(comm, lops, T, n=4000, n_keys=1, size=5, seed=3, exact=True, **kw):
     s = make_series(seed, n, n_keys)
     use_key = n_keys > 1
     y = s["x"] * 2 + 1
     tables = [dict(key=T(s["key"][sl]) if use_key else None, ts=T(s["ts"][sl]), xs=[T(s["x"][sl]), T(y[sl])],
                    xs_valid=[T(s["xv"][sl]), None], extra=[T(s["rid"][sl])])
               for sl in [chunks(n, comm.world)[r] for r in comm.local]]
-    got = timesplit.lookback_by_time(comm, tables, n_keys, size, exact, local_ops=lops)
+    got = timesplit.lookback_by_time(comm, tables, n_keys, size, exact, local_ops=lops, **kw)
     rows, lens, feat, fv = lops.lookback(T(s["key"]) if use_key else T(np.zeros(n, np.int32)), T(s["ts"]),
                                          [T(s["x"]), T(y)], [T(s["xv"]), None], n_keys, size, exact)
     fvn = None if fv is None else fv.cpu().numpy()
@@ -113,7 +118,7 @@ def compare_lookback(have, want):
             assert np.array_equal(v, wv) and np.array_equal(np.where(v != 0, f, 0), np.where(wv != 0, wf, 0))
 
 
-def check_join(comm, lops, T, n=5000, n_keys=1, seed=4, skip_nulls=True, with_seq=False):
+def check_join(comm, lops, T, n=5000, n_keys=1, seed=4, skip_nulls=True, with_seq=False, **kw):
     rng = np.random.default_rng(seed)
     L, R = make_series(seed, n, n_keys, 600), make_series(seed + 100, n, n_keys, 600)
     # long NULL stretches, so that the last non-NULL value of a column lies ranges back
@@ -130,7 +135,7 @@ def check_join(comm, lops, T, n=5000, n_keys=1, seed=4, skip_nulls=True, with_se
         m_b, m_a = T(bv[sl]), T(av[sl])
         rights.append(dict(key=K(R["key"], sl), ts=T(R["ts"][sl]), cols=[T(R["ts"][sl]), T(bid[sl]), T(ask[sl]), T(R["rid"][sl])],
                            masks=[None, m_b, m_a, m_a], **sq(sl)))
-    got = timesplit.asof_join_by_time(comm, lefts, rights, n_keys, skip_nulls, local_ops=lops)
+    got = timesplit.asof_join_by_time(comm, lefts, rights, n_keys, skip_nulls, local_ops=lops, **kw)
     zk = T(np.zeros(n, np.int32))
     full = slice(0, n)
     m_b, m_a = T(bv), T(av)
