@@ -93,12 +93,17 @@ def gen_trades_quotes(dev, n_left, n_right, n_keys, seed):
     return d
 
 
-def gen_ticks(dev, n, n_keys, seed, key_offset=0):
+def gen_ticks(dev, n, n_keys, seed, shards=1):
+    """One shard of the tick stream: n_keys symbols, one tick per second and symbol on average over
+    the whole stream.  With `shards` > 1 the stream is striped over that many ranks -- every shard
+    is time-ordered, covers the whole period and holds 1 / shards of its ticks -- so that the table
+    the ranks hold together is the same stream whatever their number (weak scaling: the period grows
+    with the ranks, the ticks per second and symbol do not)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     d = {}
     d["key"] = torch.randint(0, n_keys, (n,), generator=g, device=dev, dtype=torch.int32)
-    gaps = torch.empty(n, dtype=torch.float64, device=dev).exponential_(float(n_keys), generator=g)
+    gaps = torch.empty(n, dtype=torch.float64, device=dev).exponential_(float(n_keys) / shards, generator=g)
     d["ts"] = BASE_US + (torch.cumsum(gaps, 0) * 1e6).to(torch.int64)
     del gaps
     steps = torch.randn(n, generator=g, device=dev, dtype=torch.float64)
@@ -213,7 +218,7 @@ def main():
     ASOF_KEYS, TICK_KEYS = 10_000, 100
     log("process group up, generating tables")
     tq = gen_trades_quotes(dev, n_left, n_right, ASOF_KEYS, 4567 + rank)
-    tk = gen_ticks(dev, rows, TICK_KEYS, 2345 + rank)
+    tk = gen_ticks(dev, rows, TICK_KEYS, 2345 + rank, shards=world)
     torch.cuda.synchronize()
 
     profiling = not args.no_profile
