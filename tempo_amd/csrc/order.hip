@@ -1925,15 +1925,16 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
       radix_one_pass<1024, 12, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carry_at) *carry_at = p & 1;
     } else if (last && n_pay > 0) {
-      constexpr int kPerLaunch = 1;  // columns fetched through the row ids per launch of the last pass
-      for (int c0 = 0; c0 < n_pay; c0 += kPerLaunch) {
-        PayPtrs pp;
-        memset(&pp, 0, sizeof(pp));
-        pp.n = n_pay - c0 < kPerLaunch ? n_pay - c0 : kPerLaunch;
-        for (int c = 0; c < pp.n; ++c) { pp.src[c] = pay_src[c0 + c]; pp.out[c] = pay_out[c0 + c]; }
-        // a replay for further columns reuses the offsets of the first launch
-        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, c0 > 0, pack, id_bits);
-      }
+      // the last pass also fetches the payload through the row ids: one column with six rows per
+      // thread, two to kMaxPay columns with four (the registers that hold the fetched values bound it)
+      PayPtrs pp;
+      memset(&pp, 0, sizeof(pp));
+      pp.n = n_pay;
+      for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
+      if (n_pay == 1)
+        radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
+      else
+        radix_one_pass<1024, 4, kMaxPay>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carried) *carried = true;
     } else {
       radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none, g, false, pack, id_bits);

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_
       int64_t ibest = 0, cnt = 0;
       bool have = false;
       for (int64_t j = lo + lane; j < hi; j += 64) {
-        uint32_t r = perm[j];
+        uint32_t r = perm ? perm[j] : (uint32_t)j;
         if (valid && !valid[r]) continue;
         ++cnt;
         if (is_i) {
@@ -326,7 +326,7 @@ __device__ __forceinline__ BigAgg agg_rows(const uint32_t *perm, const ColPtrs &
   // pivot for the squared deviations: the first row's value when it is usable
   double pivot = 0.0;
   {
-    uint32_t r0 = perm[lo];
+    uint32_t r0 = perm ? perm[lo] : (uint32_t)lo;
     if (!valid || valid[r0]) {
       double v = is_i ? (double)ci[r0] : cd[r0];
       if (__builtin_isfinite(v)) pivot = v;
@@ -336,7 +336,7 @@ __device__ __forceinline__ BigAgg agg_rows(const uint32_t *perm, const ColPtrs &
   a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
   double sd = 0.0, sq = 0.0;
   for (int64_t j = lo + lane; j < hi; j += 64) {
-    uint32_t r = perm[j];
+    uint32_t r = perm ? perm[j] : (uint32_t)j;
     if (valid && !valid[r]) continue;
     double v;
     uint64_t bits;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t
       int64_t imn = 0, imx = 0, cnt = 0;
       bool have = false;
       for (int64_t j = lo + lane; j < hi; j += 64) {
-        uint32_t r = perm[j];
+        uint32_t r = perm ? perm[j] : (uint32_t)j;
         if (valid && !valid[r]) continue;
         ++cnt;
         if (is_i) {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_stats_kernel(const uint32_t
       double acc = 0.0, lin = 0.0;
       if (n > 1) {
         for (int64_t j = lo + lane; j < hi; j += 64) {
-          uint32_t r = perm[j];
+          uint32_t r = perm ? perm[j] : (uint32_t)j;
           if (valid && !valid[r]) continue;
           double d = (is_i ? (double)ci[r] : cd[r]) - mean;
           acc += d * d;
@@ -623,16 +623,77 @@ struct RbPlan {
   uint32_t *bstart;
   BigAgg *part;  // [tiles][2][n_cols] partial aggregates of big buckets
   int nblocks;
+  // up to kMaxPay metric columns are delivered in sorted order by the ordering step (xs), their
+  // validity as one byte per row (vs): the bucket kernels then read by position, front to back,
+  // instead of fetching every value through a row id
+  uint64_t *xs[kMaxPay];
+  uint8_t *vs[kMaxPay];
 };
 
-static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys) {
-  order_plan(n, ws, &p->ob, n_keys);
+static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys, bool travel = false) {
+  const int n_travel = (travel && n_cols >= 1 && n_cols <= kMaxPay) ? n_cols : 0;
+  order_plan(n, ws, &p->ob, n_keys, n_travel);
+  for (int c = 0; c < kMaxPay; ++c) {
+    p->xs[c] = c < n_travel ? ws.take<uint64_t>((size_t)(n > 0 ? n : 1)) : nullptr;
+    p->vs[c] = c < n_travel ? ws.take<uint8_t>((size_t)(n > 0 ? n : 1)) : nullptr;
+  }
   size_t cnt = (size_t)(n > 0 ? n : 1);
   p->nblocks = (int)((cnt + RB_ROWS - 1) / RB_ROWS);
   p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
   p->bstart = ws.take<uint32_t>(cnt + 1);
   size_t tiles = (cnt + BB_TILE - 1) / BB_TILE;
   p->part = ws.take<BigAgg>(tiles * 2 * (size_t)(n_cols > 0 ? n_cols : 1));
+}
+
+// out[j] = bit `slot` of the sort word at sorted position j.
+__global__ __launch_bounds__(RB_THREADS) void mask_bytes_kernel(const uint64_t *comp, int64_t n, int slot, uint8_t *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+    out[j] = (uint8_t)((comp[j] >> slot) & 1ull);
+}
+
+// Orders the rows for the bucket kernels.  Where the plan has room for them (p.xs) the metric
+// columns come out in sorted order too: *perm is then null (row j is at position j) and cp points
+// at the sorted copies; the columns' NULL masks ride in the low bits of the sort words and are
+// spread out to bytes afterwards.  Otherwise -- or when the rows were in order already, or the
+// masks do not fit the word -- *perm is the row-id permutation and cp the caller's columns.
+static int rb_order(const OrderSpec &s0, RbPlan &p, int n_cols, Layout *lay, OrderResult *res, ColPtrs *cp,
+                    const uint32_t **perm, hipStream_t st) {
+  if (p.xs[0] && n_cols >= 1 && n_cols <= kMaxPay) {
+    OrderSpec s = s0;
+    int slot_of[kMaxPay];
+    for (int k = 0; k < n_cols; ++k) {
+      slot_of[k] = -1;
+      if (cp->valid[k]) { slot_of[k] = s.n_masks; s.masks[s.n_masks++] = cp->valid[k]; }
+    }
+    TMP_TRY(order_scan_ranges(s, p.ob, st));
+    RangeInfo r;
+    TMP_TRY(order_read_ranges(p.ob, &r, st));
+    if (order_make_layout(s, r, s.n_masks, lay) == TMP_OK) {
+      const uint64_t *src[kMaxPay];
+      uint64_t *dst[kMaxPay];
+      for (int k = 0; k < n_cols; ++k) { src[k] = (const uint64_t *)cp->col[k]; dst[k] = p.xs[k]; }
+      bool carried = false;
+      TMP_TRY(order_build(s, *lay, sorted_mode(r), p.ob, res, st, n_cols, src, dst, &carried));
+      *perm = res->perm;
+      if (carried) {
+        *perm = nullptr;
+        for (int k = 0; k < n_cols; ++k) {
+          cp->col[k] = p.xs[k];
+          if (slot_of[k] >= 0) {
+            TMP_LAUNCH(mask_bytes_kernel, dim3(grid_for(s.n, RB_THREADS * 8, 8192)), dim3(RB_THREADS), st, res->comp, s.n,
+                       slot_of[k], p.vs[k]);
+            cp->valid[k] = p.vs[k];
+          }
+        }
+      }
+      return TMP_OK;
+    }
+    clear_error();  // the masks do not fit next to key and bucket: order without them
+  }
+  TMP_TRY(order_single(s0, p.ob, lay, res, st));
+  *perm = res->perm;
+  return TMP_OK;
 }
 
 }  // namespace tmp
@@ -643,7 +704,8 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
+  const bool reduce = a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX || a->func == TMP_FUNC_MEAN;
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce);
   return ws.off;
 }
 
@@ -669,7 +731,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -681,7 +743,6 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   s.prim_div = reduce ? a->dur_us : 1;
   Layout lay;
   OrderResult res;
-  TMP_TRY(order_single(s, p.ob, &lay, &res, st));
   ColPtrs cp;
   memset(&cp, 0, sizeof(cp));
   for (int k = 0; k < a->n_cols; ++k) {
@@ -690,6 +751,8 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     cp.valid[k] = a->col_valid[k];
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
+  const uint32_t *perm = nullptr;
+  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st));
   TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, dur,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
@@ -698,12 +761,12 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
              p.block_counts, p.bstart, a->out_key, a->out_start);
   if (reduce) {
     if (a->n_cols > 0) {
-      TMP_LAUNCH(bucket_reduce_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
+      TMP_LAUNCH(bucket_reduce_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, perm,
                  p.bstart, a->out_count, a->func, a->n_cols, cp, a->n, a->out_f64, a->out_i64, a->out_valid,
                  (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
       if (a->n > BB_BIG) {  // only then can a bucket be a big one
         TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
-                   dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
+                   dim3(RB_THREADS), st, perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
                    (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
         TMP_LAUNCH(bucket_big_reduce_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
                    dim3(RB_THREADS), st, p.bstart, a->out_count, a->func, a->n_cols, cp, p.part, a->n,
@@ -722,7 +785,7 @@ extern "C" size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true);
   return ws.off;
 }
 
@@ -745,7 +808,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
               TMP_EINVAL, "tmp_grouped_stats: column or output arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys));
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -753,7 +816,6 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
   s.prim_div = a->dur_us;  // ordered by (key, bucket index): the statistics ignore the order inside a bucket
   Layout lay;
   OrderResult res;
-  TMP_TRY(order_single(s, p.ob, &lay, &res, st));
   ColPtrs cp;
   memset(&cp, 0, sizeof(cp));
   for (int k = 0; k < a->n_cols; ++k) {
@@ -762,6 +824,8 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     cp.valid[k] = a->col_valid[k];
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
+  const uint32_t *perm = nullptr;
+  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st));
   TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, (int64_t)1,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,
@@ -772,11 +836,11 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     StatsOut o;
     o.mean = a->out_mean; o.n = a->out_n; o.mn = (uint64_t *)a->out_min; o.mx = (uint64_t *)a->out_max;
     o.sum = (uint64_t *)a->out_sum; o.stddev = a->out_stddev;
-    TMP_LAUNCH(bucket_stats_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, res.perm,
+    TMP_LAUNCH(bucket_stats_kernel, dim3(grid_for(a->n, RB_THREADS, 8192)), dim3(RB_THREADS), st, perm,
                p.bstart, a->out_count, a->n_cols, cp, a->n, o, (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
     if (a->n > BB_BIG) {
       TMP_LAUNCH(bucket_big_tiles_kernel, dim3(grid_for(a->n, BB_TILE * (RB_THREADS / 64), 1 << 16)),
-                 dim3(RB_THREADS), st, res.perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
+                 dim3(RB_THREADS), st, perm, p.bstart, a->out_count, a->n, a->n_cols, cp, p.part,
                    (int64_t)(a->key && a->n_keys > 1 ? a->n_keys : 1));
       TMP_LAUNCH(bucket_big_stats_kernel, dim3(grid_for(a->n, BB_BIG * (RB_THREADS / 64), 4096)),
                  dim3(RB_THREADS), st, p.bstart, a->out_count, a->n_cols, cp, p.part, a->n, o);
