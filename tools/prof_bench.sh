@@ -12,9 +12,9 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-profile --no-shuffled > $O/fetch.log 2>&1
 timeout -s KILL 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-profile --no-shuffled > $O/write.log 2>&1
 cd $R
-S=$(find $O/trace -name '*kernel_stats.csv' | head -1)
-F=$(find $O/fetch -name '*counter_collection.csv' | head -1)
-W=$(find $O/write -name '*counter_collection.csv' | head -1)
+S=$(ls -t $O/trace/*/*kernel_stats.csv | head -1)
+F=$(ls -t $O/fetch/*/*counter_collection.csv | head -1)
+W=$(ls -t $O/write/*/*counter_collection.csv | head -1)
 python3 profiles/summarize_pmc.py $S $F $W $O/${TAG}_bench1b_pmc_traffic.json > $O/summary.txt
 cp $S $O/${TAG}_bench1b_kernel_stats.csv
 tail -1 $O/trace.log > $O/${TAG}_bench1b_traced.json

@@ -11,10 +11,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/tools/bench_ops.py --rows $ROWS --reps 1 --no-profile > $O/fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/tools/bench_ops.py --rows $ROWS --reps 1 --no-profile > $O/write.log 2>&1
 cd $R
-S=$(find $O/trace -name '*kernel_stats.csv' | head -1)
-F=$(find $O/fetch -name '*counter_collection.csv' | head -1)
-W=$(find $O/write -name '*counter_collection.csv' | head -1)
-python3 profiles/summarize_ops.py $S $F $W $ROWS $O/r02_ops_pmc.json
+S=$(ls -t $O/trace/*/*kernel_stats.csv | head -1)
+F=$(ls -t $O/fetch/*/*counter_collection.csv | head -1)
+W=$(ls -t $O/write/*/*counter_collection.csv | head -1)
+T=$(ls -t $O/trace/*/*kernel_trace.csv | head -1)
+python3 profiles/summarize_ops.py $T $F $W $ROWS $O/r02_ops_pmc.json
 cp $S $O/r02_ops_kernel_stats.csv
 timeout -k 10 300 python3 tools/bench_ops.py --rows 500000000 > $O/r02_ops.jsonl 2> $O/ops.err
 tail -3 $O/r02_ops.jsonl
