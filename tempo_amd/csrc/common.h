@@ -209,6 +209,16 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
 // One-call form for ops that order a single table.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st);
+// Orders one table and, where it can, delivers n_cols (1..kMaxPay) 8-byte columns in sorted order
+// as well: xs[c][p] = cols[c][perm[p]], and for the columns that have a NULL mask vs[c][p] = its
+// byte at that row (the masks ride in the low bits of the sort words and are spread out to bytes
+// afterwards).  *traveled says whether that happened -- not when the rows were in order already
+// (perm is then the identity) or the masks do not fit the word; the order itself is always built.
+// `b` must have been planned with carry_cols >= n_cols for the columns to travel with a bucketed sort.
+int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64_t *const *cols,
+                  const uint8_t *const *valid, uint64_t *const *xs, uint8_t *const *vs, Layout *lay,
+                  OrderResult *res, bool *traveled, hipStream_t st);
+
 // Layouts with ext_masks: out[p] = validity bits (bit m = mask m) of the row at sorted position p.
 int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out, hipStream_t st);
 

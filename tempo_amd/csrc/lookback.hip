@@ -146,7 +146,7 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_wide_kernel(
     double val = 0.0;
     uint8_t ok = 0;
     if (l < m) {
-      uint32_t src = perm[p - m + l];
+      uint32_t src = perm ? perm[p - m + l] : (uint32_t)(p - m + l);
       ok = fp.v[f] ? fp.v[f][src] : 1;
       val = ok ? fp.x[f][src] : 0.0;
     }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
   uint8_t *okv = lb_smem + (size_t)cap * n_feat * 8;   // [n_feat][cap]
   if (staged) {
     for (uint32_t sl = threadIdx.x; sl < span; sl += LB_THREADS) {
-      const uint32_t src = perm[first + sl];
+      const uint32_t src = perm ? perm[first + sl] : first + sl;
       for (int f = 0; f < n_feat; ++f) {
         const uint8_t ok = fp.v[f] ? fp.v[f][src] : 1;
         okv[(size_t)f * cap + sl] = ok;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
         ok = okv[(size_t)f * cap + (at - first)];
         val = xv[(size_t)f * cap + (at - first)];
       } else {
-        const uint32_t src = perm[at];
+        const uint32_t src = perm ? perm[at] : at;
         ok = fp.v[f] ? fp.v[f][src] : 1;
         val = ok ? fp.x[f][src] : 0.0;
       }
@@ -257,11 +257,20 @@ struct LbPlan {
   uint32_t *block_counts;
   uint32_t *row_pos;
   int nblocks;
+  // up to kMaxPay feature columns come out of the ordering step in sorted order (values and
+  // validity bytes): the write kernels then read a history as one contiguous stretch
+  uint64_t *xs[kMaxPay];
+  uint8_t *vs[kMaxPay];
 };
 
 static void lb_plan(const tmp_lookback_args *a, Workspace &ws, LbPlan *p) {
-  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys));
+  const int n_travel = (a->n_feat >= 1 && a->n_feat <= kMaxPay) ? a->n_feat : 0;
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys), n_travel);
   size_t cnt = (size_t)(a->n > 0 ? a->n : 1);
+  for (int c = 0; c < kMaxPay; ++c) {
+    p->xs[c] = c < n_travel ? ws.take<uint64_t>(cnt) : nullptr;
+    p->vs[c] = c < n_travel ? ws.take<uint8_t>(cnt) : nullptr;
+  }
   p->nblocks = (int)((cnt + LB_ROWS - 1) / LB_ROWS);
   p->full = ws.take<uint8_t>(cnt);
   p->block_counts = ws.take<uint32_t>((size_t)p->nblocks);
@@ -306,12 +315,28 @@ extern "C" int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t 
   s.seq = a->seq; s.seq_valid = a->seq_valid;
   Layout lay;
   OrderResult res;
-  TMP_TRY(order_single(s, p.ob, &lay, &res, st));
   FeatPtrs fp;
   for (int f = 0; f < TMP_MAX_FEATURES; ++f) {
     fp.x[f] = f < a->n_feat ? a->x[f] : nullptr;
     fp.v[f] = f < a->n_feat ? a->x_valid[f] : nullptr;
     TMP_REQUIRE(f >= a->n_feat || fp.x[f], TMP_EINVAL, "tmp_lookback: feature column %d is null", f);
+  }
+  const bool fits = a->n_feat <= kMaxPay;
+  const uint64_t *src[kMaxPay];
+  const uint8_t *val[kMaxPay];
+  for (int f = 0; f < kMaxPay; ++f) {
+    src[f] = (fits && f < a->n_feat) ? (const uint64_t *)fp.x[f] : nullptr;
+    val[f] = (fits && f < a->n_feat) ? fp.v[f] : nullptr;
+  }
+  bool traveled = false;
+  TMP_TRY(order_columns(s, p.ob, fits ? a->n_feat : 0, src, val, p.xs, p.vs, &lay, &res, &traveled, st));
+  const uint32_t *feat_perm = res.perm;  // how the write kernels find a history's values
+  if (traveled) {
+    feat_perm = nullptr;
+    for (int f = 0; f < a->n_feat; ++f) {
+      fp.x[f] = (const double *)p.xs[f];
+      if (fp.v[f]) fp.v[f] = p.vs[f];
+    }
   }
   int exact = a->exact_size != 0;
   TMP_LAUNCH(lookback_count_kernel, dim3(p.nblocks), dim3(LB_THREADS), st, res.comp, a->n, lay, a->lookback,
@@ -333,13 +358,13 @@ extern "C" int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t 
     if (cap > want) cap = want;
     ProfScope ps("lookback_write_kernel", st);
     hipLaunchKernelGGL(lookback_write_kernel, dim3((unsigned)((a->n + LBW_ROWS - 1) / LBW_ROWS)), dim3(LB_THREADS),
-                       (size_t)cap * a->n_feat * 9, st, p.row_pos, res.perm, a->out_len, a->out_count, a->lookback,
+                       (size_t)cap * a->n_feat * 9, st, p.row_pos, feat_perm, a->out_len, a->out_count, a->lookback,
                        a->n_feat, exact, fp, a->out_feat, a->out_feat_valid, 1.0f / (float)per_row,
                        1.0f / (float)a->n_feat, cap);
   }
   else
     TMP_LAUNCH(lookback_write_wide_kernel, dim3(grid_for(max_elems, LB_THREADS * 8, 1 << 16)), dim3(LB_THREADS), st,
-               p.row_pos, res.perm, a->out_len, a->out_count, a->lookback, a->n_feat, exact, fp, a->out_feat,
+               p.row_pos, feat_perm, a->out_len, a->out_count, a->lookback, a->n_feat, exact, fp, a->out_feat,
                a->out_feat_valid);
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

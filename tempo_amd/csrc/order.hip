@@ -2145,6 +2145,45 @@ int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out
   return TMP_OK;
 }
 
+// out[j] = bit `slot` of the sort word at sorted position j.
+__global__ __launch_bounds__(kBlock) void mask_bytes_kernel(const uint64_t *comp, int64_t n, int slot, uint8_t *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+    out[j] = (uint8_t)((comp[j] >> slot) & 1ull);
+}
+
+int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64_t *const *cols,
+                  const uint8_t *const *valid, uint64_t *const *xs, uint8_t *const *vs, Layout *lay,
+                  OrderResult *res, bool *traveled, hipStream_t st) {
+  *traveled = false;
+  if (n_cols >= 1 && n_cols <= kMaxPay && xs && xs[0] && s0.n_masks + n_cols <= TMP_MAX_MASKS) {
+    OrderSpec s = s0;
+    int slot_of[kMaxPay];
+    for (int k = 0; k < n_cols; ++k) {
+      slot_of[k] = -1;
+      if (valid[k]) { slot_of[k] = s.n_masks; s.masks[s.n_masks++] = valid[k]; }
+    }
+    TMP_TRY(order_scan_ranges(s, b, st));
+    RangeInfo r;
+    TMP_TRY(order_read_ranges(b, &r, st));
+    if (order_make_layout(s, r, s.n_masks, lay) == TMP_OK) {
+      bool carried = false;
+      TMP_TRY(order_build(s, *lay, sorted_mode(r), b, res, st, n_cols, cols, xs, &carried));
+      if (carried) {
+        for (int k = 0; k < n_cols; ++k)
+          if (slot_of[k] >= 0)
+            TMP_LAUNCH(mask_bytes_kernel, dim3(grid_for(s.n, kBlock * 8, 8192)), dim3(kBlock), st, res->comp, s.n,
+                       slot_of[k], vs[k]);
+        TMP_CHECK_HIP(hipGetLastError());
+        *traveled = true;
+      }
+      return TMP_OK;
+    }
+    clear_error();  // the masks do not fit next to key and time: order without them
+  }
+  return order_single(s0, b, lay, res, st);
+}
+
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
                  hipStream_t st) {
   TMP_TRY(order_scan_ranges(s, b, st));

@@ -645,54 +645,29 @@ static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_k
   p->part = ws.take<BigAgg>(tiles * 2 * (size_t)(n_cols > 0 ? n_cols : 1));
 }
 
-// out[j] = bit `slot` of the sort word at sorted position j.
-__global__ __launch_bounds__(RB_THREADS) void mask_bytes_kernel(const uint64_t *comp, int64_t n, int slot, uint8_t *out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
-    out[j] = (uint8_t)((comp[j] >> slot) & 1ull);
-}
-
 // Orders the rows for the bucket kernels.  Where the plan has room for them (p.xs) the metric
-// columns come out in sorted order too: *perm is then null (row j is at position j) and cp points
-// at the sorted copies; the columns' NULL masks ride in the low bits of the sort words and are
-// spread out to bytes afterwards.  Otherwise -- or when the rows were in order already, or the
-// masks do not fit the word -- *perm is the row-id permutation and cp the caller's columns.
+// columns come out in sorted order too (order_columns): *perm is then null (row j is at position
+// j) and cp points at the sorted copies and validity bytes.  Otherwise *perm is the row-id
+// permutation and cp the caller's columns.
 static int rb_order(const OrderSpec &s0, RbPlan &p, int n_cols, Layout *lay, OrderResult *res, ColPtrs *cp,
                     const uint32_t **perm, hipStream_t st) {
-  if (p.xs[0] && n_cols >= 1 && n_cols <= kMaxPay) {
-    OrderSpec s = s0;
-    int slot_of[kMaxPay];
-    for (int k = 0; k < n_cols; ++k) {
-      slot_of[k] = -1;
-      if (cp->valid[k]) { slot_of[k] = s.n_masks; s.masks[s.n_masks++] = cp->valid[k]; }
-    }
-    TMP_TRY(order_scan_ranges(s, p.ob, st));
-    RangeInfo r;
-    TMP_TRY(order_read_ranges(p.ob, &r, st));
-    if (order_make_layout(s, r, s.n_masks, lay) == TMP_OK) {
-      const uint64_t *src[kMaxPay];
-      uint64_t *dst[kMaxPay];
-      for (int k = 0; k < n_cols; ++k) { src[k] = (const uint64_t *)cp->col[k]; dst[k] = p.xs[k]; }
-      bool carried = false;
-      TMP_TRY(order_build(s, *lay, sorted_mode(r), p.ob, res, st, n_cols, src, dst, &carried));
-      *perm = res->perm;
-      if (carried) {
-        *perm = nullptr;
-        for (int k = 0; k < n_cols; ++k) {
-          cp->col[k] = p.xs[k];
-          if (slot_of[k] >= 0) {
-            TMP_LAUNCH(mask_bytes_kernel, dim3(grid_for(s.n, RB_THREADS * 8, 8192)), dim3(RB_THREADS), st, res->comp, s.n,
-                       slot_of[k], p.vs[k]);
-            cp->valid[k] = p.vs[k];
-          }
-        }
-      }
-      return TMP_OK;
-    }
-    clear_error();  // the masks do not fit next to key and bucket: order without them
+  const uint64_t *src[kMaxPay];
+  const uint8_t *val[kMaxPay];
+  const bool fits = n_cols >= 1 && n_cols <= kMaxPay;
+  for (int k = 0; k < kMaxPay; ++k) {
+    src[k] = (fits && k < n_cols) ? (const uint64_t *)cp->col[k] : nullptr;
+    val[k] = (fits && k < n_cols) ? cp->valid[k] : nullptr;
   }
-  TMP_TRY(order_single(s0, p.ob, lay, res, st));
+  bool traveled = false;
+  TMP_TRY(order_columns(s0, p.ob, fits ? n_cols : 0, src, val, p.xs, p.vs, lay, res, &traveled, st));
   *perm = res->perm;
+  if (traveled) {
+    *perm = nullptr;
+    for (int k = 0; k < n_cols; ++k) {
+      cp->col[k] = p.xs[k];
+      if (cp->valid[k]) cp->valid[k] = p.vs[k];
+    }
+  }
   return TMP_OK;
 }
 
