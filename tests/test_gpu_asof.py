@@ -288,3 +288,44 @@ def test_asof_tables_wider_than_one_sort_word(orc, ops, nk, n_masks, seq_span, w
             got, valid = out["right"][c]
             assert np.array_equal(valid.cpu().numpy().astype(bool), ok), (what, c)
             assert np.array_equal(got.cpu().numpy(), np.where(ok, src[np.clip(j, 0, None)], 0)), (what, c)
+
+
+@pytest.mark.parametrize("order", ["per_key", "runs"])
+def test_asof_fused_table_ordered_feeds(orc, ops, order):
+    """Sides above 2^20 rows whose order lets the ordering step take a shortcut -- every key's rows
+    in time order although the table is not (interleaved feeds with jitter), or a few time-ordered
+    runs end to end (what a rank holds after a shuffle) -- with the left payload travelling along."""
+    rng = np.random.default_rng(61)
+    nk = 12
+    per = 95_000
+    n = per * nk
+
+    def side(jitter):
+        slot = np.repeat(np.arange(per, dtype=np.int64), nk)
+        key = np.tile(np.arange(nk, dtype=np.int32), per)
+        ts = BASE + slot * 1_000_000 + rng.integers(-jitter, jitter + 1, n)
+        return key, ts
+
+    key_l, ts_l = side(300_000)
+    key_r, ts_r = side(300_000)
+    if order == "runs":
+        cuts = np.r_[0, np.sort(rng.choice(np.arange(1, n), 4, replace=False)), n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            o = np.argsort(ts_l[a:b], kind="stable"); key_l[a:b], ts_l[a:b] = key_l[a:b][o], ts_l[a:b][o]
+            o = np.argsort(ts_r[a:b], kind="stable"); key_r[a:b], ts_r[a:b] = key_r[a:b][o], ts_r[a:b][o]
+        # the runs overlap in time: shuffle whole runs so that time steps back between them
+        ts_l = np.concatenate([ts_l[a:b] for a, b in list(zip(cuts[:-1], cuts[1:]))[::-1]])
+        key_l = np.concatenate([key_l[a:b] for a, b in list(zip(cuts[:-1], cuts[1:]))[::-1]])
+    mask = (rng.random(n) >= 0.3).astype(np.uint8)
+    pr = rng.normal(100, 1, n)
+    bid = rng.normal(99, 1, n)
+    out = ops.asof_join_table(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nk, [_dev(pr)],
+                              [_dev(ts_r), _dev(bid)], [None, _dev(mask)], skip_nulls=True)
+    idx, _ = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None, mask], skip_nulls=True)
+    p = out["perm"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(p, np.lexsort((np.arange(n), ts_l, key_l)))
+    assert np.array_equal(out["left"][0].cpu().numpy(), pr[p])
+    for c, (src, j) in enumerate([(ts_r, idx[0][p]), (bid, idx[1][p])]):
+        vals, valid = out["right"][c]
+        assert np.array_equal(valid.cpu().numpy().astype(bool), j >= 0), c
+        assert np.array_equal(vals.cpu().numpy(), np.where(j >= 0, src[np.clip(j, 0, None)], 0)), c
