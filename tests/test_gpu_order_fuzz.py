@@ -1,0 +1,63 @@
+"""Randomised tables through tmp_sort_order against a host sort: every shortcut the ordering step
+knows (rows in order, time-ordered feed, a few time-ordered runs, every key in order, bucketed
+sort of large random tables, plain passes) on sizes either side of the thresholds that select
+them, with and without a sequence column and the seconds cast."""
+import zlib
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+BASE = 1_596_240_000_000_000
+
+
+def _table(rng, n, n_keys, shape, step_us, span_steps):
+    key = rng.integers(0, n_keys, n).astype(np.int32)
+    ts = BASE + rng.integers(0, span_steps, n) * step_us
+    if shape == "sorted":
+        o = np.lexsort((ts, key)); key, ts = key[o], ts[o]
+    elif shape == "time":
+        ts = np.sort(ts)
+    elif shape == "runs":
+        k = int(rng.integers(2, 20))
+        cuts = np.r_[0, np.sort(rng.choice(np.arange(1, n), k - 1, replace=False)), n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ts[a:b] = np.sort(ts[a:b])
+    elif shape in ("per_key", "almost_per_key"):
+        # every key's rows in time order, the keys interleaved at random
+        where = np.argsort(key, kind="stable")          # positions of key 0's rows, then key 1's, ...
+        ts_new = np.empty_like(ts)
+        ts_new[where] = ts[np.lexsort((ts, key))]
+        ts = ts_new
+        if shape == "almost_per_key":
+            ts[rng.choice(n, 3, replace=False)] = BASE
+    return key, ts
+
+
+CASES = []
+_rng = np.random.default_rng(2024)
+for shape in ("random", "sorted", "time", "runs", "per_key", "almost_per_key"):
+    for n in (int(_rng.integers(2_000, 60_000)), int(_rng.integers(1_050_000, 1_400_000))):
+        CASES.append((shape, n, int(_rng.choice([1, 3, 40, 5000])), bool(_rng.integers(0, 2)), bool(_rng.integers(0, 2)),
+                      int(_rng.choice([1, 1000, 1_000_000]))))
+
+
+@pytest.mark.parametrize("shape,n,n_keys,with_seq,floor_seconds,step_us", CASES)
+def test_order_fuzz(orc, monkeypatch, shape, n, n_keys, with_seq, floor_seconds, step_us):
+    from tempo_amd import ops
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(zlib.crc32(repr((shape, n, n_keys)).encode()))
+    span_steps = int(rng.choice([50, 5_000, 3_000_000]))
+    key, ts = _table(rng, n, n_keys, shape, step_us, span_steps)
+    seq = sv = None
+    if with_seq:
+        seq = rng.integers(-5, 50, n)
+        sv = (rng.random(n) > 0.2).astype(np.uint8)
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    perm = ops.sort_order(d(key), d(ts), n_keys, floor_seconds=floor_seconds, seq=d(seq), seq_valid=d(sv))
+    prim = ts // 1_000_000 if floor_seconds else ts
+    sfield = np.zeros(n, np.int64) if seq is None else np.where(sv != 0, seq - seq.min() + 1, 0)
+    want = np.lexsort((np.arange(n), sfield, prim, key))
+    assert np.array_equal(perm.cpu().numpy().astype(np.int64), want)
