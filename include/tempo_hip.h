@@ -18,7 +18,12 @@
  *  - work is enqueued on `stream` (a hipStream_t); the call returns after enqueueing, except
  *    for one small device->host read of key ranges that the ordering step needs;
  *  - return value: TMP_OK or a negative TMP_E* code, message via tmp_last_error().
- *  - row counts per call are limited to 2^31-1 (row indices are int32).
+ *  - row counts per call are limited to 2^31-1 (row indices are int32);
+ *  - ordering works on one 64-bit word per row (key id, time, sequence value, NULL flags).
+ *    Sequence values and NULL flags that do not fit next to key and time are handled inside
+ *    the library (sorted in passes of their own / carried beside the words); only when key id
+ *    and time range alone need more than 64 bits does a call return TMP_EUNSUPPORTED (callers
+ *    then split the key dictionary: key order is row order, so the halves concatenate).
  */
 #ifndef TEMPO_HIP_H
 #define TEMPO_HIP_H
