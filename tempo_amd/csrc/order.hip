@@ -232,10 +232,10 @@ struct GenArgs {
   int n_masks;
   MaskPtrs masks;
   int id_bits;  // > 0: the radix passes carry the row id in that many bits below the word
-  // bucketed ordering: the top field holds key_base[key] + floor(nb * rel / (rel_max + 1)) -- the
-  // row's bucket -- instead of the key id (rel = the row's time field, inv = ceil(2^64 / (rel_max + 1)))
-  const uint32_t *key_nb;
-  const uint32_t *key_base;
+  // bucketed ordering: the top field holds base(key) + floor(nb(key) * rel / (rel_max + 1)) -- the
+  // row's bucket -- instead of the key id (rel = the row's time field, inv = ceil(2^64 / (rel_max + 1)));
+  // key_pack[key] = {nb, base}, one 8-byte gather per row
+  const uint2 *key_pack;
   uint64_t inv;
   uint32_t last_key;  // n_keys - 1: key ids beyond the dictionary are read as the last key
   int vec4;           // the columns are aligned for make_words4 (set where the words are laid out)
@@ -247,13 +247,14 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   uint64_t rel = (uint64_t)(p - lay.prim_min);
   if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
   uint64_t w = rel << lay.prim_shift();
-  if (g.key_nb) {
+  if (g.key_pack) {
     uint32_t k = g.key ? (uint32_t)g.key[i] : 0u;
     k = k < g.last_key ? k : g.last_key;
-    const uint32_t nb = g.key_nb[k];
+    const uint2 kp = g.key_pack[k];
+    const uint32_t nb = kp.x;
     uint64_t q = __umul64hi(rel * nb, g.inv);
     if (q >= nb) q = nb - 1;
-    w |= (uint64_t)(g.key_base[k] + (uint32_t)q) << lay.key_shift();
+    w |= (uint64_t)(kp.y + (uint32_t)q) << lay.key_shift();
   } else if (lay.key_bits) {
     w |= (uint64_t)(uint32_t)g.key[i] << lay.key_shift();
   }
@@ -301,13 +302,14 @@ __device__ __forceinline__ void make_words4(const GenArgs &g, int64_t i, uint64_
     if (lay.prim_gran != 1) rel[u] = (uint64_t)floordiv_i64((int64_t)rel[u], lay.prim_gran);
     w[u] = rel[u] << lay.prim_shift();
   }
-  if (g.key_nb) {
+  if (g.key_pack) {
     uint32_t nb[4], base[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t k = kk[u] < g.last_key ? kk[u] : g.last_key;
-      nb[u] = g.key_nb[k];
-      base[u] = g.key_base[k];
+      const uint2 kp = g.key_pack[k];
+      nb[u] = kp.x;
+      base[u] = kp.y;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -890,10 +892,12 @@ __global__ void bucket_nb_kernel(const unsigned long long *rows, uint32_t n_keys
   key_base[k] = (uint32_t)nb;
 }
 
-// bucket_key[b] = the key whose run of buckets holds b (largest k with key_base[k] <= b)
+// bucket_key[b] = the key whose run of buckets holds b (largest k with key_base[k] <= b); and
+// key_pack[k] = {key_nb[k], key_base[k]}, the form the sort words are built from
 __global__ void bucket_key_kernel(const uint32_t *key_base, const uint32_t *key_nb, uint32_t n_keys,
-                                  uint32_t max_buckets, uint32_t *bucket_key) {
+                                  uint32_t max_buckets, uint32_t *bucket_key, uint2 *key_pack) {
   uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t k = b; k < n_keys; k += gridDim.x * blockDim.x) key_pack[k] = make_uint2(key_nb[k], key_base[k]);
   if (b >= max_buckets) return;
   const uint32_t total = key_base[n_keys - 1] + key_nb[n_keys - 1];
   if (b >= total) return;
@@ -2081,10 +2085,9 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
              b.key_nb, b.key_base);
   TMP_TRY(scan_u32_inplace(b.key_base, (int)nk, st));
   TMP_LAUNCH(bucket_key_kernel, dim3((unsigned)((bg.max_buckets + kBlock - 1) / kBlock)), dim3(kBlock), st, b.key_base,
-             b.key_nb, nk, (uint32_t)bg.max_buckets, b.bucket_key);
+             b.key_nb, nk, (uint32_t)bg.max_buckets, b.bucket_key, reinterpret_cast<uint2 *>(b.key_rows));
   GenArgs bgen = gen;
-  bgen.key_nb = b.key_nb;
-  bgen.key_base = b.key_base;
+  bgen.key_pack = reinterpret_cast<const uint2 *>(b.key_rows);  // the sampled counts are spent by now
   bgen.last_key = nk - 1;
   const uint64_t rel_count = ((uint64_t)lay.prim_max - (uint64_t)lay.prim_min) / (uint64_t)lay.prim_gran + 1;  // R
   bgen.inv = rel_count <= 1 ? 0ull : (~0ull / rel_count) + 1;                                                // ceil(2^64 / R)
