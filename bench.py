@@ -252,6 +252,8 @@ def main():
             kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
             q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
         _lib.profile_tag(1)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        marks[0].record()
         # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
         # the left side and the three joined right columns, written by the merge itself
         j = ops.asof_join_table(
@@ -261,20 +263,30 @@ def main():
         n1 = (q["ts_l"].numel(), q["ts_r"].numel())
         log("join enqueued on %d + %d rows" % n1)
         del j
+        marks[1].record()
         _lib.profile_tag(2)
         if dist is not None:
             kk, (tt, xx, xv), _, _ = p_ticks.wait()
             t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
+        marks[2].record()
         out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
         n2 = t["ts"].numel()
         log("range stats enqueued on %d rows" % n2)
         del out
+        marks[3].record()
+        op_marks.append(marks)
         return n1, n2
+
+    # per operator: events on the stream the operators are called on, before and after each; the
+    # join orders its two sides on two streams at once, so the sum of its kernels' own durations
+    # would count the overlapped time twice
+    op_marks = []
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     _lib.profile_reset()
+    del op_marks[:]
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -323,6 +335,8 @@ def main():
             # range-stats launches cover `rows` (single-GPU layout; per-rank counts differ by
             # the key hash under --gpus N and are close to these)
             k["rows"] += (rows / 2 if tag == 1 else rows)
+        op_ms[1] = sum(m[0].elapsed_time(m[1]) for m in op_marks)
+        op_ms[2] = sum(m[2].elapsed_time(m[3]) for m in op_marks)
         dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         name, k = dom
         bpr = KERNEL_BYTES_PER_ROW.get(name)
@@ -382,7 +396,7 @@ def main():
         if roofline is not None:
             roofline["step_algorithmic_bytes"] = step_bytes
             roofline["step_frac_of_peak"] = round(step_bytes / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)
-            # per operator: compulsory bytes / device time of the operator's kernels (rank 0) / peak
+            # per operator: compulsory bytes / device time between the events around it (rank 0) / peak
             per_op = {}
             for name, tag, nbytes in (("asofJoin", 1, asof_bytes), ("withRangeStats", 2, stats_bytes)):
                 ms = op_ms.get(tag, 0.0) / args.steps

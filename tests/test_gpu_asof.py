@@ -329,3 +329,38 @@ def test_asof_fused_table_ordered_feeds(orc, ops, order):
         vals, valid = out["right"][c]
         assert np.array_equal(valid.cpu().numpy().astype(bool), j >= 0), c
         assert np.array_equal(vals.cpu().numpy(), np.where(j >= 0, src[np.clip(j, 0, None)], 0)), c
+
+
+def test_asof_right_side_on_its_own_stream(orc, ops, monkeypatch):
+    """TEMPO_JOIN_STREAMS=1 orders the right side on the library's own stream, forked from and joined
+    back into the caller's: the joined table is the oracle's, twice in a row (the stream and its
+    events are reused), and equal to what the single-stream call returns."""
+    rng = np.random.default_rng(67)
+    nk, n = 40, 1_200_000
+    key_l = rng.integers(0, nk, n).astype(np.int32)
+    key_r = rng.integers(0, nk, n).astype(np.int32)
+    ts_l = BASE + rng.integers(0, 3_600_000_000, n)
+    ts_r = BASE + rng.integers(0, 3_600_000_000, n)
+    mask = (rng.random(n) >= 0.2).astype(np.uint8)
+    pr, bid, ask = rng.normal(100, 1, n), rng.normal(99, 1, n), rng.normal(101, 1, n)
+
+    def run():
+        return ops.asof_join_table(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nk, [_dev(pr)],
+                                   [_dev(ts_r), _dev(bid), _dev(ask)], [None, _dev(mask), None],
+                                   skip_nulls=True, ts_partition_val=10, fraction=0.1)
+
+    monkeypatch.delenv("TEMPO_JOIN_STREAMS", raising=False)
+    one = run()
+    monkeypatch.setenv("TEMPO_JOIN_STREAMS", "1")
+    idx, _ = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None, mask], skip_nulls=True,
+                           ts_partition_val=10, fraction=0.1)
+    for _ in range(2):
+        two = run()
+        p = two["perm"].cpu().numpy().astype(np.int64)
+        assert np.array_equal(p, one["perm"].cpu().numpy())
+        assert np.array_equal(two["left"][0].cpu().numpy(), pr[p])
+        for c, (src, j) in enumerate([(ts_r, idx[0][p]), (bid, idx[1][p]), (ask, idx[0][p])]):
+            vals, valid = two["right"][c]
+            assert np.array_equal(valid.cpu().numpy().astype(bool), j >= 0), c
+            assert np.array_equal(vals.cpu().numpy(), np.where(j >= 0, src[np.clip(j, 0, None)], 0)), c
+            assert np.array_equal(vals.cpu().numpy(), one["right"][c][0].cpu().numpy()), c
