@@ -327,7 +327,8 @@ def main():
     if profiling:
         rows_of = {1: None, 2: None}
         for name, tag, ms in _lib.profile_read():
-            k = kernels.setdefault(name, dict(launches=0, ms=0.0, rows=0.0))
+            k = kernels.setdefault(name, dict(launches=0, ms=0.0, rows=0.0, op=False))
+            k["op"] = k["op"] or tag in (1, 2)
             k["launches"] += 1
             k["ms"] += ms
             op_ms[tag] = op_ms.get(tag, 0.0) + ms
@@ -337,8 +338,10 @@ def main():
             k["rows"] += (rows / 2 if tag == 1 else rows)
         op_ms[1] = sum(m[0].elapsed_time(m[1]) for m in op_marks)
         op_ms[2] = sum(m[2].elapsed_time(m[3]) for m in op_marks)
-        dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
-        name, k = dom
+        # the dominant kernel of the two operators (the routing kernels of the shuffle under --gpus N
+        # are listed in top_kernels_ms_per_step, they are not the path's kernel)
+        of_ops = {n: k for n, k in kernels.items() if k["op"]} or kernels
+        name, k = max(of_ops.items(), key=lambda kv: kv[1]["ms"])
         bpr = KERNEL_BYTES_PER_ROW.get(name)
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes
         # (FETCH_SIZE and WRITE_SIZE, separate runs of this command at the default size)

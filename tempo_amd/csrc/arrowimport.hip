@@ -153,6 +153,8 @@ extern "C" int tmp_arrow_import(const struct ArrowArray *array, const struct Arr
         nulls += !((bitmap[b >> 3] >> (b & 7)) & 1);
       }
   }
+  TMP_REQUIRE(nulls == 0 || bitmap, TMP_EINVAL, "tmp_arrow_import: the array counts NULLs but has no validity bitmap");
+  TMP_REQUIRE(nulls <= n, TMP_EINVAL, "tmp_arrow_import: null_count exceeds the length");
   if (out_null_count) *out_null_count = nulls;
   if (n == 0) return TMP_OK;
   TMP_REQUIRE(array->n_buffers >= 2 && array->buffers && array->buffers[1], TMP_EINVAL,
