@@ -278,12 +278,20 @@ constexpr int kMergeRight = 768 * kMergeRows;  // right sort words staged in LDS
 // Block = 1024 consecutive rows of the ordered left side.  Their positions in the ordered right
 // side all fall between the positions of the block's first and last row; that slice of right
 // sort words is staged in LDS (when it fits) and every row binary-searches it there.
+//
+// NC, NM > 0: the launch has at most NC joined columns and NM masks; the loops over them are then
+// unrolled, which turns every per-column field of the argument block (rule, slot, pointers) into a
+// constant-offset scalar load made once, instead of one indexed load -- and one wait for it -- per
+// column, mask and row.  NC = NM = 0: any number, loops as written.
+template <int NC, int NM>
 __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     const uint64_t *comp_l, const uint32_t *perm_l, int64_t n_left, const uint64_t *comp_r,
     const uint32_t *perm_r, int64_t n_right, Layout lay, int n_masks, const int32_t *lastnn,
     SkewParams sp, int32_t *out_idx, int32_t *out_missing, int sorted_output, int32_t *out_perm,
     int32_t *out_key, int64_t *out_ts, JoinCols jc, const int64_t *block_bounds, const uint16_t *cmask) {
   __shared__ uint64_t rw[kMergeRight];
+  constexpr int kColLoop = NC > 0 ? NC : TMP_MAX_JOIN_COLS, kColUnroll = NC > 0 ? NC : 1;
+  constexpr int kMaskLoop = NM > 0 ? NM : TMP_MAX_MASKS, kMaskUnroll = NM > 0 ? NM : 1;
   const int low = lay.low_bits;
   int64_t tile = (int64_t)blockIdx.x * (kBlock * kMergeRows);
   int64_t tile_end = tile + kBlock * kMergeRows < n_left ? tile + kBlock * kMergeRows : n_left;
@@ -385,7 +393,9 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       }
       // validity bits of the matched row: the low bits of its word, or the separate array
       const uint64_t mrow = cmask ? (jrow >= 0 ? (uint64_t)cmask[jrow] : 0ull) : wr_row;
-      for (int c = 0; c < jc.n; ++c) {  // columns that follow the row rule
+#pragma unroll kColUnroll
+      for (int c = 0; c < kColLoop; ++c) {  // columns that follow the row rule
+        if (c >= jc.n) break;
         if (jc.rule[c] >= 0) continue;
         bool okv = jrow >= 0 && (jc.vmask[c] < 0 || ((mrow >> jc.vmask[c]) & 1ull));
         const int sl = jc.slot[c];
@@ -395,7 +405,11 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
         if (jc.out_valid[c]) jc.out_valid[c][dst] = okv ? 1 : 0;
       }
     }
-    for (int m = 0; m < n_masks; ++m) {
+#pragma unroll kMaskUnroll
+    for (int m = 0; m < kMaskLoop; ++m) {
+      // guarded, not left by a break: with the inline asm below the loop only unrolls when its trip
+      // count is exact
+      if (m >= n_masks) continue;
       int64_t jm = -1;  // position of the last visible row whose mask m is valid, or -1
       uint64_t wm = 0;
       if (same) {
@@ -421,7 +435,9 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       miss_mask |= (uint32_t)(jm < 0) << m;
       const uint64_t *rm = nullptr;
       const uint64_t mm = cmask ? (jm >= 0 ? (uint64_t)cmask[jm] : 0ull) : wm;
-      for (int c = 0; c < jc.n; ++c) {
+#pragma unroll kColUnroll
+      for (int c = 0; c < kColLoop; ++c) {
+        if (c >= jc.n) break;
         if (jc.rule[c] != m) continue;
         bool okv = jm >= 0 && (jc.vmask[c] < 0 || ((mm >> jc.vmask[c]) & 1ull));
         uint64_t v = 0;
@@ -726,9 +742,17 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(merge_bounds_kernel, dim3((grid + 1 + kBlock - 1) / kBlock), dim3(kBlock), st, lo.comp, a->n_left, ro.comp,
              a->n_right, lay.low_bits, kBlock * kMergeRows, (int64_t)grid, p.block_bounds);
-  TMP_LAUNCH(asof_merge_kernel, dim3(grid), dim3(kBlock), st, lo.comp, lo.perm, a->n_left,
-                     ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                     a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
+  {
+    ProfScope ps("asof_merge_kernel", st);
+    if (jc.n <= 4 && a->n_masks <= 4)
+      hipLaunchKernelGGL((asof_merge_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+                         ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
+                         a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
+    else
+      hipLaunchKernelGGL((asof_merge_kernel<0, 0>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+                         ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
+                         a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
+  }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
 }

@@ -21,10 +21,21 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="left + right rows")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--order", choices=["random", "sorted", "time"], default="random",
+                    help="row order of both sides: as generated (random), by (key, ts), or by ts alone")
+    ap.add_argument("--no-skew", action="store_true", help="plain join: no tsPartitionVal brackets")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = args.rows // 2
     q = bench.gen_trades_quotes(dev, n, n, 10_000, 4567)
+    if args.order != "random":
+        for side, cols in (("l", ["key_l", "ts_l", "trade_pr"]), ("r", ["key_r", "ts_r", "bid", "ask", "bid_valid", "ask_valid"])):
+            o = torch.argsort(q["ts_" + side], stable=True)
+            if args.order == "sorted":
+                o = o[torch.argsort(q["key_" + side][o], stable=True)]
+            for c in cols:
+                q[c] = q[c][o].contiguous()
+            del o
     torch.cuda.synchronize()
     if not args.no_profile:
         _lib.profile_enable(True)
@@ -32,7 +43,7 @@ def main():
     def run():
         return ops.asof_join_table(q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], 10_000, [q["trade_pr"]],
                                    [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
-                                   skip_nulls=True, ts_partition_val=10, fraction=0.1)
+                                   skip_nulls=True, ts_partition_val=None if args.no_skew else 10, fraction=0.1)
 
     run()
     torch.cuda.synchronize()
@@ -50,7 +61,7 @@ def main():
             k = kern.setdefault(name, [0, 0.0])
             k[0] += 1
             k[1] += ms / args.reps
-    print(json.dumps(dict(rows=args.rows, ms_per_call=round(e0.elapsed_time(e1) / args.reps, 3),
+    print(json.dumps(dict(rows=args.rows, order=args.order, ms_per_call=round(e0.elapsed_time(e1) / args.reps, 3),
                           kernels={k: dict(launches=v[0] // args.reps, ms=round(v[1], 3))
                                    for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])})))
 
