@@ -364,3 +364,31 @@ def test_asof_right_side_on_its_own_stream(orc, ops, monkeypatch):
             assert np.array_equal(valid.cpu().numpy().astype(bool), j >= 0), c
             assert np.array_equal(vals.cpu().numpy(), np.where(j >= 0, src[np.clip(j, 0, None)], 0)), c
             assert np.array_equal(vals.cpu().numpy(), one["right"][c][0].cpu().numpy()), c
+
+
+@pytest.mark.parametrize("skip_nulls", [True, False])
+def test_asof_fused_table_many_columns(orc, ops, skip_nulls):
+    """More joined columns and masks than the merge's unrolled instance takes (six columns, five
+    of them with NULLs): the general instance writes the same table."""
+    rng = np.random.default_rng(73)
+    nL, nR, nk, nm = 50_000, 40_000, 11, 5
+    key_l, ts_l, key_r, ts_r, _, _, masks = _make(rng, nL, nR, nk, 900 * 1_000_000, 1000, nm, 0.25, False)
+    pr = rng.normal(100, 1, nL)
+    cols = [rng.normal(50 + c, 1, nR) for c in range(nm)]
+    out = ops.asof_join_table(_dev(key_l), _dev(ts_l), _dev(key_r), _dev(ts_r), nk, [_dev(pr)],
+                              [_dev(ts_r)] + [_dev(c) for c in cols], [None] + [_dev(m) for m in masks],
+                              skip_nulls=skip_nulls)
+    idx, omiss = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None] + masks, skip_nulls=skip_nulls)
+    p = out["perm"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(p, np.lexsort((np.arange(nL), ts_l, key_l)))
+    assert np.array_equal(out["left"][0].cpu().numpy(), pr[p])
+    for c, (src, j, mask) in enumerate([(ts_r, idx[0], None)] + [(cols[m], idx[1 + m], masks[m]) for m in range(nm)]):
+        j = j[p]
+        ok = j >= 0
+        if mask is not None and not skip_nulls:
+            ok = ok & (mask[np.clip(j, 0, None)] == 1)
+        vals, valid = out["right"][c]
+        assert np.array_equal(valid.cpu().numpy().astype(bool), ok), c
+        assert np.array_equal(vals.cpu().numpy(), np.where(ok, src[np.clip(j, 0, None)], 0)), c
+    if skip_nulls:
+        assert out["missing"].cpu().numpy().tolist() == omiss.tolist()
