@@ -1871,6 +1871,11 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
   }
 }
 
+#ifndef TEMPO_RS_ITEMS
+#define TEMPO_RS_ITEMS 12
+#endif
+constexpr int kPlainItems = TEMPO_RS_ITEMS;  // rows per thread of the passes that move pairs (and travelling columns) only
+
 template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
                            const PayPtrs &pp, const GenArgs *gen, bool hist_done, int pack, int id_bits) {
@@ -1926,7 +1931,7 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
         pp.src[c] = p == 0 ? pay_src[c] : carry_buf[2 * c + ((p - 1) & 1)];
         pp.out[c] = carry_buf[2 * c + (p & 1)];
       }
-      radix_one_pass<1024, 12, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
+      radix_one_pass<1024, kPlainItems, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carry_at) *carry_at = p & 1;
     } else if (last && n_pay > 0) {
       // the last pass also fetches the payload through the row ids: one column with six rows per
@@ -1941,7 +1946,7 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
         radix_one_pass<1024, 4, kMaxPay>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carried) *carried = true;
     } else {
-      radix_one_pass<1024, 12, 0>(b, n, cur, lo, nbits, st, none, g, false, pack, id_bits);
+      radix_one_pass<1024, kPlainItems, 0>(b, n, cur, lo, nbits, st, none, g, false, pack, id_bits);
     }
     lo += nbits;
     cur ^= 1;
