@@ -406,9 +406,10 @@ def resample(key, ts, n_keys, dur_us, func, cols, cols_valid):
     out_start = torch.empty(cap, dtype=torch.int64, device=dev)
     reduce_func = func in ("min", "max", "mean")
     kk = max(k, 1) if reduce_func else 1
-    out_f64 = torch.zeros((kk, cap), dtype=torch.float64, device=dev)
-    out_i64 = torch.zeros((kk, cap), dtype=torch.int64, device=dev)
-    out_valid = torch.zeros((kk, cap), dtype=torch.uint8, device=dev)
+    # every cell of the first `count` buckets is written by the call; nothing beyond them is read
+    out_f64 = torch.empty((kk, cap), dtype=torch.float64, device=dev)
+    out_i64 = torch.empty((kk, cap), dtype=torch.int64, device=dev)
+    out_valid = torch.empty((kk, cap), dtype=torch.uint8, device=dev)
     out_row = torch.empty(cap, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     a = ResampleArgs(n, _p(key), int(n_keys), _p(ts), int(dur_us), _lib.FUNC_CODES[func], k,
