@@ -297,6 +297,13 @@ int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t workspace_b
  *   floor / ceil  -> out_row[b] = input row with the smallest / largest (ts, cols...) tuple
  *                    under Spark struct ordering (NULL smallest, NaN greatest)
  * out_valid[c*n + b] = result not NULL (mean/min/max).
+ * mean of at most 4 columns over at most 2048 keys and 2^20 (key, bucket) cells between the
+ * table's first and last bucket, on 2^20 rows or more that arrive in some time order (or fall
+ * into at most 512 cells): the rows are not ordered at all; every row adds its values to its
+ * cell with double-precision atomic adds, so the last bits of such a mean depend on the order in
+ * which the hardware performed the adds and may differ between two runs (the count, the bucket
+ * membership and the NULL flags do not).  TEMPO_NO_DENSE_MEAN=1 in the environment keeps every
+ * mean on the ordered path.
  */
 #define TMP_FUNC_FLOOR 0
 #define TMP_FUNC_MIN 1

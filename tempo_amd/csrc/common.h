@@ -207,8 +207,10 @@ int order_radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Order
                        hipStream_t st, int n_pay = 0, const uint64_t *const *pay_src = nullptr,
                        uint64_t *const *pay_out = nullptr, bool *carried = nullptr);
 // One-call form for ops that order a single table.
+// known: the table's ranges as order_scan_ranges / order_read_ranges gave them for this very
+// OrderSpec (NULL masks aside); the scan is then not repeated.
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
-                 hipStream_t st);
+                 hipStream_t st, const RangeInfo *known = nullptr);
 // Orders one table and, where it can, delivers n_cols (1..kMaxPay) 8-byte columns in sorted order
 // as well: xs[c][p] = cols[c][perm[p]], and for the columns that have a NULL mask vs[c][p] = its
 // byte at that row (the masks ride in the low bits of the sort words and are spread out to bytes
@@ -217,7 +219,7 @@ int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *
 // `b` must have been planned with carry_cols >= n_cols for the columns to travel with a bucketed sort.
 int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64_t *const *cols,
                   const uint8_t *const *valid, uint64_t *const *xs, uint8_t *const *vs, Layout *lay,
-                  OrderResult *res, bool *traveled, hipStream_t st);
+                  OrderResult *res, bool *traveled, hipStream_t st, const RangeInfo *known = nullptr);
 
 // Layouts with ext_masks: out[p] = validity bits (bit m = mask m) of the row at sorted position p.
 int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out, hipStream_t st);

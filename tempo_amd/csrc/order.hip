@@ -2162,7 +2162,7 @@ __global__ __launch_bounds__(kBlock) void mask_bytes_kernel(const uint64_t *comp
 
 int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64_t *const *cols,
                   const uint8_t *const *valid, uint64_t *const *xs, uint8_t *const *vs, Layout *lay,
-                  OrderResult *res, bool *traveled, hipStream_t st) {
+                  OrderResult *res, bool *traveled, hipStream_t st, const RangeInfo *known) {
   *traveled = false;
   if (n_cols >= 1 && n_cols <= kMaxPay && xs && xs[0] && s0.n_masks + n_cols <= TMP_MAX_MASKS) {
     OrderSpec s = s0;
@@ -2171,9 +2171,13 @@ int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64
       slot_of[k] = -1;
       if (valid[k]) { slot_of[k] = s.n_masks; s.masks[s.n_masks++] = valid[k]; }
     }
-    TMP_TRY(order_scan_ranges(s, b, st));
     RangeInfo r;
-    TMP_TRY(order_read_ranges(b, &r, st));
+    if (known) {
+      r = *known;
+    } else {
+      TMP_TRY(order_scan_ranges(s, b, st));
+      TMP_TRY(order_read_ranges(b, &r, st));
+    }
     if (order_make_layout(s, r, s.n_masks, lay) == TMP_OK) {
       bool carried = false;
       TMP_TRY(order_build(s, *lay, sorted_mode(r), b, res, st, n_cols, cols, xs, &carried));
@@ -2189,14 +2193,18 @@ int order_columns(const OrderSpec &s0, OrderBuffers &b, int n_cols, const uint64
     }
     clear_error();  // the masks do not fit next to key and time: order without them
   }
-  return order_single(s0, b, lay, res, st);
+  return order_single(s0, b, lay, res, st, known);
 }
 
 int order_single(const OrderSpec &s, OrderBuffers &b, Layout *lay, OrderResult *res,
-                 hipStream_t st) {
-  TMP_TRY(order_scan_ranges(s, b, st));
+                 hipStream_t st, const RangeInfo *known) {
   RangeInfo r;
-  TMP_TRY(order_read_ranges(b, &r, st));
+  if (known) {
+    r = *known;
+  } else {
+    TMP_TRY(order_scan_ranges(s, b, st));
+    TMP_TRY(order_read_ranges(b, &r, st));
+  }
   TMP_TRY(order_make_layout(s, r, s.n_masks, lay));
   return order_build(s, *lay, sorted_mode(r), b, res, st);
 }

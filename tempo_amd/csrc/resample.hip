@@ -628,11 +628,193 @@ struct RbPlan {
   // instead of fetching every value through a row id
   uint64_t *xs[kMaxPay];
   uint8_t *vs[kMaxPay];
+  // mean over few (key, bucket) cells: the cells' row counts, value counts and sums (see dense_mean_kernel)
+  uint32_t *d_rows;
+  uint32_t *d_cnt;
+  double *d_sum;
 };
 
-static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys, bool travel = false) {
+// ------------------------------------------------------------------------------------------
+// mean without ordering the rows.  The mean of a bucket does not depend on the order of its rows,
+// and a table of (keys) x (buckets between the first and the last timestamp) cells is small when
+// the feed covers hours or days in minute buckets: every row adds its values to its cell, and the
+// non-empty cells, taken in (key, bucket) order, are the result.  Cells are reached through a
+// hash table in LDS, one per block and flushed to the table in global memory when it fills up --
+// a block works through a contiguous stretch of rows, which in a time-ordered feed touches a
+// handful of cells.  The sums are double-precision atomic adds: their order, and with it the
+// last bits of a mean, may differ from run to run.
+// ------------------------------------------------------------------------------------------
+constexpr int kDenseCols = 4;                  // metric columns per call
+constexpr int64_t kDenseGroups = 1 << 20;      // cells of the table
+constexpr int64_t kDenseKeys = 2048;           // keys: a stretch of a feed may touch every one of them
+constexpr int DH_SLOTS = 1024;                 // slots of a block's hash table
+constexpr int DH_THREADS = 1024;
+constexpr int DH_ROWS = 4;                     // rows per thread and step
+constexpr int DH_PROBES = 16;                  // slots tried before a row goes to the global table itself
+constexpr uint32_t DH_EMPTY = 0xffffffffu;
+// Tables below this many rows take the ordered path (TEMPO_DENSE_MIN_ROWS overrides: tests).
+static int64_t dense_min_rows() {
+  const char *e = getenv("TEMPO_DENSE_MIN_ROWS");
+  return e ? (int64_t)atoll(e) : (int64_t)(1 << 20);
+}
+
+struct DenseTab {
+  uint32_t *rows;  // [cells]
+  uint32_t *cnt;   // [n_cols][cells]; columns with a NULL mask only (the others have `rows` values)
+  double *sum;     // [n_cols][cells]
+  int64_t cells;
+};
+
+__global__ __launch_bounds__(DH_THREADS) void dense_mean_kernel(const int32_t *key, const int64_t *ts, int64_t n,
+                                                                int64_t dur, int64_t bmin, uint32_t per_key,
+                                                                int n_cols, ColPtrs cols, DenseTab tab) {
+  __shared__ uint32_t h_cell[DH_SLOTS];
+  __shared__ uint32_t h_rows[DH_SLOTS];
+  __shared__ uint32_t h_cnt[kDenseCols][DH_SLOTS];
+  __shared__ double h_sum[kDenseCols][DH_SLOTS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < DH_SLOTS; i += DH_THREADS) {
+    h_cell[i] = DH_EMPTY;
+    h_rows[i] = 0;
+#pragma unroll
+    for (int c = 0; c < kDenseCols; ++c) { h_cnt[c][i] = 0; h_sum[c][i] = 0.0; }
+  }
+  __syncthreads();
+  // the block's stretch of rows, in steps of DH_THREADS * DH_ROWS; the waves run through it on
+  // their own (no barrier): a cell that finds no slot within DH_PROBES tries -- the stretch
+  // touches more cells than the table holds -- is added to the global table directly
+  constexpr int kStep = DH_THREADS * DH_ROWS;
+  const int64_t steps = (n + kStep - 1) / kStep;
+  const int64_t per_block = (steps + gridDim.x - 1) / gridDim.x;
+  const int64_t s0 = (int64_t)blockIdx.x * per_block;
+  const int64_t s1 = s0 + per_block < steps ? s0 + per_block : steps;
+  for (int64_t st = s0; st < s1; ++st) {
+    int64_t row[DH_ROWS];
+    int64_t t[DH_ROWS];
+    uint32_t k[DH_ROWS];
+    double v[DH_ROWS][kDenseCols];
+    bool ok[DH_ROWS][kDenseCols];
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      row[r] = st * kStep + r * DH_THREADS + tid;
+      const bool live = row[r] < n;
+      const int64_t at = live ? row[r] : n - 1;
+      t[r] = ts[at];
+      k[r] = key ? (uint32_t)key[at] : 0u;
+#pragma unroll
+      for (int c = 0; c < kDenseCols; ++c) {
+        v[r][c] = 0.0;
+        ok[r][c] = false;
+        if (c >= n_cols) continue;
+        const uint8_t *valid = cols.valid[c];
+        ok[r][c] = live && (!valid || valid[at]);
+        v[r][c] = cols.is_i64[c] ? (double)((const int64_t *)cols.col[c])[at] : ((const double *)cols.col[c])[at];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      if (row[r] >= n) continue;
+      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
+      uint32_t slot = (g * 2654435761u) >> 22;  // top 10 bits
+      bool found = false;
+      for (int probe = 0; probe < DH_PROBES; ++probe) {
+        const uint32_t old = atomicCAS(&h_cell[slot], DH_EMPTY, g);
+        if (old == DH_EMPTY || old == g) { found = true; break; }
+        slot = (slot + 1) & (DH_SLOTS - 1);
+      }
+      if (found) {
+        atomicAdd(&h_rows[slot], 1u);
+#pragma unroll
+        for (int c = 0; c < kDenseCols; ++c) {
+          if (c >= n_cols || !ok[r][c]) continue;
+          if (cols.valid[c]) atomicAdd(&h_cnt[c][slot], 1u);  // without NULLs: as many values as rows
+          atomicAdd(&h_sum[c][slot], v[r][c]);
+        }
+      } else {
+        atomicAdd(&tab.rows[g], 1u);
+#pragma unroll
+        for (int c = 0; c < kDenseCols; ++c) {
+          if (c >= n_cols || !ok[r][c]) continue;
+          if (cols.valid[c]) atomicAdd(&tab.cnt[(size_t)c * tab.cells + g], 1u);
+          atomicAdd(&tab.sum[(size_t)c * tab.cells + g], v[r][c]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < DH_SLOTS; i += DH_THREADS) {
+    const uint32_t g = h_cell[i];
+    if (g == DH_EMPTY) continue;
+    atomicAdd(&tab.rows[g], h_rows[i]);
+#pragma unroll
+    for (int c = 0; c < kDenseCols; ++c) {
+      if (c >= n_cols) continue;
+      if (cols.valid[c]) {
+        if (!h_cnt[c][i]) continue;
+        atomicAdd(&tab.cnt[(size_t)c * tab.cells + g], h_cnt[c][i]);
+      }
+      atomicAdd(&tab.sum[(size_t)c * tab.cells + g], h_sum[c][i]);
+    }
+  }
+}
+
+// The non-empty cells in (key, bucket) order: one block, every thread a contiguous stretch of cells.
+__global__ __launch_bounds__(1024) void dense_emit_kernel(DenseTab tab, int n_cols, uint32_t masked, uint32_t per_key, int64_t bmin,
+                                                          int64_t dur, int64_t cap, int32_t *out_key,
+                                                          int64_t *out_start, double *out_f64, int64_t *out_i64,
+                                                          uint8_t *out_valid, int64_t *out_count) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (tab.cells + 1023) / 1024;
+  const int64_t c0 = (int64_t)tid * per;
+  const int64_t c1 = c0 + per < tab.cells ? c0 + per : tab.cells;
+  uint32_t mine = 0;
+  for (int64_t g = c0; g < c1; ++g) mine += tab.rows[g] != 0;
+  uint32_t inc = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t at = inc - mine;
+  uint32_t total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) at += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0) *out_count = (int64_t)total;
+  for (int64_t g = c0; g < c1; ++g) {
+    if (tab.rows[g] == 0) continue;
+    out_key[at] = (int32_t)(g / per_key);
+    out_start[at] = (bmin + (int64_t)(g % per_key)) * dur;
+    for (int c = 0; c < n_cols; ++c) {
+      // values of the cell: counted for a column with NULLs, else the cell's rows
+      const uint32_t cnt = ((masked >> c) & 1u) ? tab.cnt[(size_t)c * tab.cells + g] : tab.rows[g];
+      const int64_t o = (int64_t)c * cap + at;
+      out_valid[o] = cnt > 0;
+      out_f64[o] = cnt ? tab.sum[(size_t)c * tab.cells + g] / (double)cnt : 0.0;
+      out_i64[o] = 0;
+    }
+    ++at;
+  }
+}
+
+static bool dense_planned(int64_t n, int n_cols, int64_t n_keys, bool mean) {
+  return mean && n >= dense_min_rows() && n_cols >= 1 && n_cols <= kDenseCols && n_keys <= kDenseKeys;
+}
+
+static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys, bool travel = false,
+                    bool mean = false) {
   const int n_travel = (travel && n_cols >= 1 && n_cols <= kMaxPay) ? n_cols : 0;
   order_plan(n, ws, &p->ob, n_keys, n_travel);
+  p->d_rows = p->d_cnt = nullptr;
+  p->d_sum = nullptr;
+  if (dense_planned(n, n_cols, n_keys, mean)) {
+    p->d_sum = ws.take<double>((size_t)kDenseGroups * n_cols);
+    p->d_rows = ws.take<uint32_t>((size_t)kDenseGroups);
+    p->d_cnt = ws.take<uint32_t>((size_t)kDenseGroups * n_cols);
+  }
   for (int c = 0; c < kMaxPay; ++c) {
     p->xs[c] = c < n_travel ? ws.take<uint64_t>((size_t)(n > 0 ? n : 1)) : nullptr;
     p->vs[c] = c < n_travel ? ws.take<uint8_t>((size_t)(n > 0 ? n : 1)) : nullptr;
@@ -650,7 +832,7 @@ static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_k
 // j) and cp points at the sorted copies and validity bytes.  Otherwise *perm is the row-id
 // permutation and cp the caller's columns.
 static int rb_order(const OrderSpec &s0, RbPlan &p, int n_cols, Layout *lay, OrderResult *res, ColPtrs *cp,
-                    const uint32_t **perm, hipStream_t st) {
+                    const uint32_t **perm, hipStream_t st, const RangeInfo *known = nullptr) {
   const uint64_t *src[kMaxPay];
   const uint8_t *val[kMaxPay];
   const bool fits = n_cols >= 1 && n_cols <= kMaxPay;
@@ -659,7 +841,7 @@ static int rb_order(const OrderSpec &s0, RbPlan &p, int n_cols, Layout *lay, Ord
     val[k] = (fits && k < n_cols) ? cp->valid[k] : nullptr;
   }
   bool traveled = false;
-  TMP_TRY(order_columns(s0, p.ob, fits ? n_cols : 0, src, val, p.xs, p.vs, lay, res, &traveled, st));
+  TMP_TRY(order_columns(s0, p.ob, fits ? n_cols : 0, src, val, p.xs, p.vs, lay, res, &traveled, st, known));
   *perm = res->perm;
   if (traveled) {
     *perm = nullptr;
@@ -680,7 +862,7 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   Workspace ws(nullptr, 0);
   RbPlan p;
   const bool reduce = a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX || a->func == TMP_FUNC_MEAN;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN);
   return ws.off;
 }
 
@@ -706,7 +888,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -727,7 +909,39 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
   const uint32_t *perm = nullptr;
-  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st));
+  RangeInfo range;
+  const RangeInfo *known = nullptr;
+  if (p.d_rows) {
+    // mean over few cells: no ordering at all (the ranges are read either way)
+    TMP_TRY(order_scan_ranges(s, p.ob, st));
+    TMP_TRY(order_read_ranges(p.ob, &range, st));
+    known = &range;
+    const int64_t nk = plan_keys(a->key, a->n_keys);
+    const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;  // buckets first .. last
+    // rows that lie close together should fall into few cells (what overflows a block's table is
+    // added to the global one row by row): a feed in some time order -- or so few cells that a
+    // block's table holds them all
+    const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DH_SLOTS / 2;
+    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+        !getenv("TEMPO_NO_DENSE_MEAN")) {
+      DenseTab tab;
+      tab.cells = (int64_t)((uint64_t)nk * per_key);
+      tab.rows = p.d_rows; tab.cnt = p.d_cnt; tab.sum = p.d_sum;
+      TMP_CHECK_HIP(hipMemsetAsync(tab.rows, 0, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.cnt, 0, sizeof(uint32_t) * tab.cells * a->n_cols, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.sum, 0, sizeof(double) * tab.cells * a->n_cols, st));
+      TMP_LAUNCH(dense_mean_kernel, dim3(grid_for(a->n, DH_THREADS * DH_ROWS * 8, 2048)), dim3(DH_THREADS), st,
+                 a->key, a->ts, a->n, a->dur_us, range.prim_min, (uint32_t)per_key, a->n_cols, cp, tab);
+      uint32_t masked = 0;
+      for (int k = 0; k < a->n_cols; ++k)
+        if (cp.valid[k]) masked |= 1u << k;
+      TMP_LAUNCH(dense_emit_kernel, dim3(1), dim3(1024), st, tab, a->n_cols, masked, (uint32_t)per_key, range.prim_min,
+                 a->dur_us, a->n, a->out_key, a->out_start, a->out_f64, a->out_i64, a->out_valid, a->out_count);
+      TMP_CHECK_HIP(hipGetLastError());
+      return TMP_OK;
+    }
+  }
+  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st, known));
   TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, dur,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,

@@ -353,3 +353,38 @@ def test_lookback_very_long_history(orc, ops):
     assert np.array_equal(rows.cpu().numpy().astype(np.int64), operm)
     assert np.array_equal(lens.cpu().numpy(), olen)
     assert np.array_equal(feat.cpu().numpy(), ofeat) and np.array_equal(fv.cpu().numpy(), ofv)
+
+
+@pytest.mark.parametrize("feed", ["time_ordered", "sorted", "random_few_cells", "random_many_cells", "many_keys",
+                                  "single_series"])
+def test_resample_mean_without_ordering(orc, ops, feed, monkeypatch):
+    """mean over a table of (key, bucket) cells, rows added where they lie: time-ordered and sorted
+    feeds, a random one whose cells fit a block's table, many keys (the block tables fill up and
+    are flushed), a table without keys; a random feed over many cells takes the ordered path.
+    NULLs, an integer column, timestamps before the epoch."""
+    monkeypatch.setenv("TEMPO_DENSE_MIN_ROWS", "1")
+    rng = np.random.default_rng(91)
+    n = 400_000
+    nk = {"many_keys": 700, "random_few_cells": 4, "single_series": 1}.get(feed, 9)
+    dur = 60_000_000
+    span = {"random_few_cells": 100 * dur, "many_keys": 300 * dur}.get(feed, 2000 * dur)
+    ts = -3 * dur + np.sort(rng.integers(0, span, n))          # starts before the epoch
+    key = rng.integers(0, nk, n).astype(np.int32)
+    if feed == "sorted":
+        o = np.lexsort((ts, key)); key, ts = key[o], ts[o]
+    if feed.startswith("random"):
+        o = rng.permutation(n); key, ts = key[o], ts[o]
+    a = rng.normal(-1.7, 3.86, n)
+    b = rng.integers(-10**9, 10**9, n)
+    c = 1e6 + rng.normal(0, 1e-3, n)
+    av = (rng.random(n) >= 0.3).astype(np.uint8)
+    cols, valid = [a, b, c], [av, None, None]
+    k_dev = None if feed == "single_series" else _dev(key)
+    r = ops.resample(k_dev, _dev(ts), nk, dur, "mean", [_dev(x) for x in cols], [_dev(v) for v in valid])
+    e = orc.resample(None if feed == "single_series" else key, ts, dur, "mean", cols, valid)
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"])
+    assert np.array_equal(r["start"].cpu().numpy(), e["start"])
+    assert np.array_equal(r["valid"].cpu().numpy(), e["valid"])
+    np.testing.assert_allclose(r["f64"].cpu().numpy(), e["f64"], rtol=1e-9, atol=1e-12)
+    assert not r["i64"].cpu().numpy().any()
