@@ -24,6 +24,8 @@ ALGO = {
     "ema_kernel": 8 + 8 + 8 + 4,
     # resample(mean, 3 cols): the 3 metric columns, already in sorted order (outputs are per bucket)
     "bucket_reduce_kernel": 3 * 8,
+    # resample(mean) without ordering: key + ts + the 3 metric columns in (outputs are per bucket)
+    "dense_mean_kernel": 4 + 8 + 3 * 8,
     "bucket_count_kernel": 8,
     "bucket_starts_kernel": 8,
     # withGroupedStats(1 col): the metric column in sorted order
