@@ -409,6 +409,11 @@ int tmp_interpolate(const tmp_interpolate_args *a, void *workspace, size_t works
  *                                                        NULL when out_n == 0
  *   out_stddev sample standard deviation                 NULL when out_n < 2
  * NULLs are not flagged separately: out_n says which cells are NULL.
+ * One or two columns over few cells on a feed in some time order (the conditions of tmp_resample's
+ * mean, with 256 cells where it says 512) are not ordered either: two sweeps over the rows as
+ * they lie, atomic adds for the sums (last bits of mean / double sum / stddev may differ between
+ * two runs), integer atomics for counts, integer sums, minima and maxima (exact; a NaN extreme
+ * comes back as the canonical quiet NaN).  TEMPO_NO_DENSE_STATS=1 keeps the ordered path.
  */
 typedef struct {
   int64_t n;

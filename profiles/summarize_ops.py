@@ -26,6 +26,8 @@ ALGO = {
     "bucket_reduce_kernel": 3 * 8,
     # resample(mean) without ordering: key + ts + the 3 metric columns in (outputs are per bucket)
     "dense_mean_kernel": 4 + 8 + 3 * 8,
+    # withGroupedStats(1 col) without ordering: key + ts + the metric column in, per sweep
+    "dense_stats_kernel": 4 + 8 + 8,
     "bucket_count_kernel": 8,
     "bucket_starts_kernel": 8,
     # withGroupedStats(1 col): the metric column in sorted order

@@ -617,6 +617,20 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_big_stats_kernel(const uint
   }
 }
 
+// Cells of withGroupedStats without ordering (dense_stats_kernel).
+struct StatTab {
+  uint32_t *rows;   // [cells]
+  uint32_t *cnt;    // [n_cols][cells] values that are not NULL
+  double *sum;      // [n_cols][cells] sum of the values as doubles; after the mean pass: the mean
+  uint64_t *isum;   // [n_cols][cells] exact sum (integer columns)
+  uint64_t *mn;     // [n_cols][cells] coded minimum (starts at all ones)
+  uint64_t *mx;     // [n_cols][cells] coded maximum (starts at zero)
+  double *total;    // [n_cols][cells] the sum, kept when `sum` becomes the mean
+  double *acc;      // [n_cols][cells] sum of squared deviations from the mean
+  double *lin;      // [n_cols][cells] sum of deviations
+  int64_t cells;
+};
+
 struct RbPlan {
   OrderBuffers ob;
   uint32_t *block_counts;
@@ -632,6 +646,7 @@ struct RbPlan {
   uint32_t *d_rows;
   uint32_t *d_cnt;
   double *d_sum;
+  StatTab st;  // withGroupedStats over few cells (see dense_stats_kernel); null pointers: not planned
 };
 
 // ------------------------------------------------------------------------------------------
@@ -800,12 +815,225 @@ __global__ __launch_bounds__(1024) void dense_emit_kernel(DenseTab tab, int n_co
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// withGroupedStats without ordering the rows: the same table of cells, two sweeps over the rows.
+// Sweep A adds every row to its cell's count, sum, exact integer sum, minimum and maximum (the
+// extremes as order-preserving 64-bit codes, so that they are integer atomics); a pass over the
+// cells turns the sums into means; sweep B adds the deviations from the cell's mean and their
+// squares (the corrected two-pass form of the ordered path).
+// ------------------------------------------------------------------------------------------
+constexpr int kStatCols = 2;
+constexpr int DS_SLOTS = 512;
+
+// Spark's ordering of doubles as unsigned integers: -inf < ... < -0.0 < 0.0 < ... < inf < NaN.
+__device__ __forceinline__ uint64_t code_f64(double v) {
+  if (v != v) return ~0ull;
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+__device__ __forceinline__ uint64_t decode_f64(uint64_t e) {  // the double's bits
+  if (e == ~0ull) return 0x7ff8000000000000ull;
+  return (e >> 63) ? (e & ~(1ull << 63)) : ~e;
+}
+__device__ __forceinline__ uint64_t code_i64(int64_t v) { return (uint64_t)v ^ (1ull << 63); }
+
+
+// SWEEP 0: counts, sums, extremes.  SWEEP 1: deviations from tab.sum (the means by then).
+template <int SWEEP>
+__global__ __launch_bounds__(DH_THREADS) void dense_stats_kernel(const int32_t *key, const int64_t *ts, int64_t n,
+                                                                 int64_t dur, int64_t bmin, uint32_t per_key,
+                                                                 int n_cols, ColPtrs cols, StatTab tab) {
+  __shared__ uint32_t h_cell[DS_SLOTS];
+  __shared__ uint32_t h_rows[DS_SLOTS];
+  __shared__ uint32_t h_cnt[kStatCols][DS_SLOTS];
+  __shared__ double h_a[kStatCols][DS_SLOTS];    // sweep 0: sum; sweep 1: squared deviations
+  __shared__ double h_b[kStatCols][DS_SLOTS];    // sweep 1: deviations
+  __shared__ uint64_t h_i[kStatCols][DS_SLOTS];  // sweep 0: exact integer sum
+  __shared__ uint64_t h_mn[kStatCols][DS_SLOTS];
+  __shared__ uint64_t h_mx[kStatCols][DS_SLOTS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < DS_SLOTS; i += DH_THREADS) {
+    h_cell[i] = DH_EMPTY;
+    h_rows[i] = 0;
+#pragma unroll
+    for (int c = 0; c < kStatCols; ++c) {
+      h_cnt[c][i] = 0; h_a[c][i] = 0.0; h_b[c][i] = 0.0; h_i[c][i] = 0; h_mn[c][i] = ~0ull; h_mx[c][i] = 0ull;
+    }
+  }
+  __syncthreads();
+  constexpr int kStep = DH_THREADS * DH_ROWS;
+  const int64_t steps = (n + kStep - 1) / kStep;
+  const int64_t per_block = (steps + gridDim.x - 1) / gridDim.x;
+  const int64_t s0 = (int64_t)blockIdx.x * per_block;
+  const int64_t s1 = s0 + per_block < steps ? s0 + per_block : steps;
+  for (int64_t st = s0; st < s1; ++st) {
+    int64_t row[DH_ROWS], t[DH_ROWS];
+    uint32_t k[DH_ROWS];
+    uint64_t raw[DH_ROWS][kStatCols];
+    bool ok[DH_ROWS][kStatCols];
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      row[r] = st * kStep + r * DH_THREADS + tid;
+      const bool live = row[r] < n;
+      const int64_t at = live ? row[r] : n - 1;
+      t[r] = ts[at];
+      k[r] = key ? (uint32_t)key[at] : 0u;
+#pragma unroll
+      for (int c = 0; c < kStatCols; ++c) {
+        raw[r][c] = 0;
+        ok[r][c] = false;
+        if (c >= n_cols) continue;
+        const uint8_t *valid = cols.valid[c];
+        ok[r][c] = live && (!valid || valid[at]);
+        raw[r][c] = ((const uint64_t *)cols.col[c])[at];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      if (row[r] >= n) continue;
+      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
+      uint32_t slot = (g * 2654435761u) >> 23;  // top 9 bits
+      bool found = false;
+      for (int probe = 0; probe < DH_PROBES; ++probe) {
+        const uint32_t old = atomicCAS(&h_cell[slot], DH_EMPTY, g);
+        if (old == DH_EMPTY || old == g) { found = true; break; }
+        slot = (slot + 1) & (DS_SLOTS - 1);
+      }
+      if (SWEEP == 0) {
+        if (found) atomicAdd(&h_rows[slot], 1u);
+        else atomicAdd(&tab.rows[g], 1u);
+      }
+#pragma unroll
+      for (int c = 0; c < kStatCols; ++c) {
+        if (c >= n_cols || !ok[r][c]) continue;
+        const bool is_i = cols.is_i64[c] != 0;
+        const double v = is_i ? (double)(int64_t)raw[r][c] : __longlong_as_double((long long)raw[r][c]);
+        const size_t at = (size_t)c * tab.cells + g;
+        if (SWEEP == 0) {
+          const uint64_t code = is_i ? code_i64((int64_t)raw[r][c]) : code_f64(v);
+          if (found) {
+            atomicAdd(&h_cnt[c][slot], 1u);
+            atomicAdd(&h_a[c][slot], v);
+            if (is_i) atomicAdd((unsigned long long *)&h_i[c][slot], (unsigned long long)raw[r][c]);
+            atomicMin((unsigned long long *)&h_mn[c][slot], (unsigned long long)code);
+            atomicMax((unsigned long long *)&h_mx[c][slot], (unsigned long long)code);
+          } else {
+            atomicAdd(&tab.cnt[at], 1u);
+            atomicAdd(&tab.sum[at], v);
+            if (is_i) atomicAdd((unsigned long long *)&tab.isum[at], (unsigned long long)raw[r][c]);
+            atomicMin((unsigned long long *)&tab.mn[at], (unsigned long long)code);
+            atomicMax((unsigned long long *)&tab.mx[at], (unsigned long long)code);
+          }
+        } else {
+          const double d = v - tab.sum[at];  // the cell's mean
+          if (found) {
+            atomicAdd(&h_a[c][slot], d * d);
+            atomicAdd(&h_b[c][slot], d);
+          } else {
+            atomicAdd(&tab.acc[at], d * d);
+            atomicAdd(&tab.lin[at], d);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < DS_SLOTS; i += DH_THREADS) {
+    const uint32_t g = h_cell[i];
+    if (g == DH_EMPTY) continue;
+    if (SWEEP == 0 && h_rows[i]) atomicAdd(&tab.rows[g], h_rows[i]);
+#pragma unroll
+    for (int c = 0; c < kStatCols; ++c) {
+      if (c >= n_cols) continue;
+      const size_t at = (size_t)c * tab.cells + g;
+      if (SWEEP == 0) {
+        if (!h_cnt[c][i]) continue;
+        atomicAdd(&tab.cnt[at], h_cnt[c][i]);
+        atomicAdd(&tab.sum[at], h_a[c][i]);
+        if (cols.is_i64[c]) atomicAdd((unsigned long long *)&tab.isum[at], (unsigned long long)h_i[c][i]);
+        atomicMin((unsigned long long *)&tab.mn[at], (unsigned long long)h_mn[c][i]);
+        atomicMax((unsigned long long *)&tab.mx[at], (unsigned long long)h_mx[c][i]);
+      } else {
+        atomicAdd(&tab.acc[at], h_a[c][i]);
+        atomicAdd(&tab.lin[at], h_b[c][i]);
+      }
+    }
+  }
+}
+
+// Between the sweeps: the cells' sums become their means (the sums are kept beside them).
+__global__ __launch_bounds__(kBlock) void dense_stats_means_kernel(StatTab tab, int n_cols) {
+  const int64_t total = tab.cells * n_cols;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const uint32_t cnt = tab.cnt[i];
+    tab.total[i] = tab.sum[i];
+    tab.sum[i] = cnt ? tab.sum[i] / (double)cnt : 0.0;
+  }
+}
+
+// The non-empty cells in (key, bucket) order with their statistics: one block.
+__global__ __launch_bounds__(1024) void dense_stats_emit_kernel(StatTab tab, int n_cols, ColPtrs cols, uint32_t per_key,
+                                                                int64_t bmin, int64_t dur, int64_t cap,
+                                                                int32_t *out_key, int64_t *out_start, StatsOut o,
+                                                                int64_t *out_count) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (tab.cells + 1023) / 1024;
+  const int64_t c0 = (int64_t)tid * per;
+  const int64_t c1 = c0 + per < tab.cells ? c0 + per : tab.cells;
+  uint32_t mine = 0;
+  for (int64_t g = c0; g < c1; ++g) mine += tab.rows[g] != 0;
+  uint32_t inc = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t at = inc - mine;
+  uint32_t total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) at += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0) *out_count = (int64_t)total;
+  for (int64_t g = c0; g < c1; ++g) {
+    if (tab.rows[g] == 0) continue;
+    out_key[at] = (int32_t)(g / per_key);
+    out_start[at] = (bmin + (int64_t)(g % per_key)) * dur;
+    for (int c = 0; c < n_cols; ++c) {
+      const size_t i = (size_t)c * tab.cells + g;
+      const int64_t n = tab.cnt[i];
+      const int64_t w = (int64_t)c * cap + at;
+      o.n[w] = n;
+      o.mean[w] = tab.sum[i];
+      double sd = 0.0;
+      if (n > 1) {
+        const double m2 = tab.acc[i] - tab.lin[i] * tab.lin[i] / (double)n;
+        sd = m2 != m2 ? m2 : sqrt((m2 < 0.0 ? 0.0 : m2) / (double)(n - 1));
+      }
+      o.stddev[w] = sd;
+      if (cols.is_i64[c]) {
+        o.mn[w] = n > 0 ? (tab.mn[i] ^ (1ull << 63)) : 0ull;
+        o.mx[w] = n > 0 ? (tab.mx[i] ^ (1ull << 63)) : 0ull;
+        o.sum[w] = n > 0 ? tab.isum[i] : 0ull;
+      } else {
+        o.mn[w] = n > 0 ? decode_f64(tab.mn[i]) : 0ull;
+        o.mx[w] = n > 0 ? decode_f64(tab.mx[i]) : 0ull;
+        o.sum[w] = n > 0 ? (uint64_t)__double_as_longlong(tab.total[i]) : 0ull;
+      }
+    }
+    ++at;
+  }
+}
+
 static bool dense_planned(int64_t n, int n_cols, int64_t n_keys, bool mean) {
   return mean && n >= dense_min_rows() && n_cols >= 1 && n_cols <= kDenseCols && n_keys <= kDenseKeys;
 }
 
 static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys, bool travel = false,
-                    bool mean = false) {
+                    bool mean = false, bool stats = false) {
   const int n_travel = (travel && n_cols >= 1 && n_cols <= kMaxPay) ? n_cols : 0;
   order_plan(n, ws, &p->ob, n_keys, n_travel);
   p->d_rows = p->d_cnt = nullptr;
@@ -814,6 +1042,19 @@ static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_k
     p->d_sum = ws.take<double>((size_t)kDenseGroups * n_cols);
     p->d_rows = ws.take<uint32_t>((size_t)kDenseGroups);
     p->d_cnt = ws.take<uint32_t>((size_t)kDenseGroups * n_cols);
+  }
+  memset(&p->st, 0, sizeof(p->st));
+  if (stats && n >= dense_min_rows() && n_cols >= 1 && n_cols <= kStatCols && n_keys <= kDenseKeys) {
+    const size_t cells = (size_t)kDenseGroups, all = cells * (size_t)n_cols;
+    p->st.sum = ws.take<double>(all);
+    p->st.total = ws.take<double>(all);
+    p->st.acc = ws.take<double>(all);
+    p->st.lin = ws.take<double>(all);
+    p->st.isum = ws.take<uint64_t>(all);
+    p->st.mn = ws.take<uint64_t>(all);
+    p->st.mx = ws.take<uint64_t>(all);
+    p->st.rows = ws.take<uint32_t>(cells);
+    p->st.cnt = ws.take<uint32_t>(all);
   }
   for (int c = 0; c < kMaxPay; ++c) {
     p->xs[c] = c < n_travel ? ws.take<uint64_t>((size_t)(n > 0 ? n : 1)) : nullptr;
@@ -974,7 +1215,7 @@ extern "C" size_t tmp_grouped_stats_workspace_bytes(const tmp_grouped_stats_args
   if (!a) return 0;
   Workspace ws(nullptr, 0);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true, false, true);
   return ws.off;
 }
 
@@ -997,7 +1238,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
               TMP_EINVAL, "tmp_grouped_stats: column or output arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), true, false, true);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_grouped_stats: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -1014,7 +1255,45 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     cp.is_i64[k] = a->col_is_i64[k] ? 1 : 0;
   }
   const uint32_t *perm = nullptr;
-  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st));
+  RangeInfo range;
+  const RangeInfo *known = nullptr;
+  if (p.st.rows) {
+    // few (key, bucket) cells and a feed in some time order: two sweeps over the rows as they lie
+    TMP_TRY(order_scan_ranges(s, p.ob, st));
+    TMP_TRY(order_read_ranges(p.ob, &range, st));
+    known = &range;
+    const int64_t nk = plan_keys(a->key, a->n_keys);
+    const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;
+    const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DS_SLOTS / 2;
+    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+        !getenv("TEMPO_NO_DENSE_STATS")) {
+      StatTab tab = p.st;
+      tab.cells = (int64_t)((uint64_t)nk * per_key);
+      const size_t all = (size_t)tab.cells * a->n_cols;
+      TMP_CHECK_HIP(hipMemsetAsync(tab.rows, 0, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.cnt, 0, sizeof(uint32_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.sum, 0, sizeof(double) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.acc, 0, sizeof(double) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.lin, 0, sizeof(double) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.isum, 0, sizeof(uint64_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.mx, 0, sizeof(uint64_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.mn, 0xff, sizeof(uint64_t) * all, st));
+      const int grid = grid_for(a->n, DH_THREADS * DH_ROWS * 8, 2048);
+      StatsOut o;
+      o.mean = a->out_mean; o.n = a->out_n; o.mn = (uint64_t *)a->out_min; o.mx = (uint64_t *)a->out_max;
+      o.sum = (uint64_t *)a->out_sum; o.stddev = a->out_stddev;
+      TMP_LAUNCH(dense_stats_kernel<0>, dim3(grid), dim3(DH_THREADS), st, a->key, a->ts, a->n, a->dur_us,
+                 range.prim_min, (uint32_t)per_key, a->n_cols, cp, tab);
+      TMP_LAUNCH(dense_stats_means_kernel, dim3(grid_for((int64_t)all, kBlock, 4096)), dim3(kBlock), st, tab, a->n_cols);
+      TMP_LAUNCH(dense_stats_kernel<1>, dim3(grid), dim3(DH_THREADS), st, a->key, a->ts, a->n, a->dur_us,
+                 range.prim_min, (uint32_t)per_key, a->n_cols, cp, tab);
+      TMP_LAUNCH(dense_stats_emit_kernel, dim3(1), dim3(1024), st, tab, a->n_cols, cp, (uint32_t)per_key,
+                 range.prim_min, a->dur_us, a->n, a->out_key, a->out_start, o, a->out_count);
+      TMP_CHECK_HIP(hipGetLastError());
+      return TMP_OK;
+    }
+  }
+  TMP_TRY(rb_order(s, p, a->n_cols, &lay, &res, &cp, &perm, st, known));
   TMP_LAUNCH(bucket_count_kernel, dim3(p.nblocks), dim3(RB_THREADS), st, res.comp, a->n, lay, (int64_t)1,
              p.block_counts);
   TMP_LAUNCH(bucket_offsets_kernel, dim3(1), dim3(1024), st, p.block_counts, p.nblocks, a->out_count,

@@ -388,3 +388,50 @@ def test_resample_mean_without_ordering(orc, ops, feed, monkeypatch):
     assert np.array_equal(r["valid"].cpu().numpy(), e["valid"])
     np.testing.assert_allclose(r["f64"].cpu().numpy(), e["f64"], rtol=1e-9, atol=1e-12)
     assert not r["i64"].cpu().numpy().any()
+
+
+@pytest.mark.parametrize("feed", ["time_ordered", "sorted", "random_few_cells", "random_many_cells", "many_keys",
+                                  "single_series"])
+@pytest.mark.parametrize("dur", [60_000_000, 86_400_000_000])
+def test_grouped_stats_without_ordering(orc, ops, feed, dur, monkeypatch):
+    """withGroupedStats over a table of (key, bucket) cells, two sweeps over the rows as they lie:
+    counts, minima, maxima and integer sums bit-exact, mean / double sum / stddev within 1e-9 --
+    NULLs, NaNs (greatest under Spark's ordering), an integer column, timestamps before the
+    epoch; a random feed over many cells takes the ordered path."""
+    monkeypatch.setenv("TEMPO_DENSE_MIN_ROWS", "1")
+    rng = np.random.default_rng(97)
+    n = 300_000
+    nk = {"many_keys": 700, "random_few_cells": 4, "single_series": 1}.get(feed, 9)
+    minute = 60_000_000
+    span = {"random_few_cells": 100 * minute, "many_keys": 300 * minute}.get(feed, 2000 * minute)
+    ts = -3 * minute + np.sort(rng.integers(0, span, n))
+    key = rng.integers(0, nk, n).astype(np.int32)
+    if feed == "sorted":
+        o = np.lexsort((ts, key)); key, ts = key[o], ts[o]
+    if feed.startswith("random"):
+        o = rng.permutation(n); key, ts = key[o], ts[o]
+    xd = 100 + np.cumsum(rng.normal(0, 0.01, n))
+    xd[rng.random(n) < 0.0005] = np.nan
+    xd[rng.random(n) < 0.0005] = -np.inf
+    xi = rng.integers(-10**12, 10**12, n)
+    vd = (rng.random(n) > 0.05).astype(np.uint8)
+    vi = (rng.random(n) > 0.5).astype(np.uint8)
+    k_dev = None if feed == "single_series" else _dev(key)
+    r = ops.grouped_stats(k_dev, _dev(ts), nk, dur, [_dev(xd), _dev(xi)], [_dev(vd), _dev(vi)])
+    e = orc.grouped_stats(None if feed == "single_series" else key, ts, dur, [xd, xi], [vd, vi])
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["start"].cpu().numpy(), e["start"])
+    for c in range(2):
+        cnt = r["count"][c].cpu().numpy()
+        assert np.array_equal(cnt, e["count"][c]), c
+        ok, ok2 = cnt > 0, cnt > 1
+        for name in ("min", "max"):
+            assert np.array_equal(r[name][c].cpu().numpy()[ok], e[name][c][ok], equal_nan=True), (c, name)
+        if e["is_i64"][c]:
+            assert np.array_equal(r["sum"][c].cpu().numpy()[ok], e["sum"][c][ok])
+        else:
+            np.testing.assert_allclose(r["sum"][c].cpu().numpy()[ok], e["sum"][c][ok], rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(r["mean"][c].cpu().numpy()[ok], e["mean"][c][ok], rtol=1e-9, equal_nan=True)
+        scale = 1e12 if e["is_i64"][c] else 100.0
+        np.testing.assert_allclose(r["stddev"][c].cpu().numpy()[ok2], e["stddev"][c][ok2], rtol=1e-9,
+                                   atol=1e-12 * scale, equal_nan=True)
