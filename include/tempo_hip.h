@@ -200,9 +200,24 @@ typedef struct {
   double *out_stddev;
   double *out_zscore;
   uint8_t *out_valid;
+  /* != 0: the caller takes the result rows in whatever order the call finds cheapest, out_perm
+   * saying which input row each one belongs to.  A feed in time order over few (key, second)
+   * cells is then not ordered at all (see below) and comes back in its own row order. */
+  int32_t any_order;
 } tmp_range_stats_args;
 
-/* Two workspace sizes.  The plain one serves every table whose frames stay inside a block's
+/* any_order: a double metric on 2^22 rows or more that arrive in time order (keys interleaved),
+ * over at most 2^24 (key, second) cells between the first and the last second and at most 4096
+ * keys, is aggregated per cell (two sweeps over the rows as they lie: count, sum, minimum, maximum;
+ * then the squared deviations from the cell's mean); the cells of every key are combined forwards
+ * and backwards inside blocks of range_back_secs + 1 seconds (counts and sums add, minima and
+ * maxima compare, (count, mean, M2) merge as Spark's own CentralMomentAgg merges partial
+ * aggregates), so that a row's frame is the union of at most two such runs; a last sweep writes
+ * every row's statistics where the row lies (out_perm[i] = i).  Tables with NaN or infinite
+ * values, and everything else, take the ordered path.  The sums are atomic adds: last bits of
+ * mean / sum / stddev / zscore may differ between two runs.
+ *
+ * Two workspace sizes.  The plain one serves every table whose frames stay inside a block's
  * on-chip region (about 1280 rows back from a row, 256 same-second rows after it).  If some
  * frame is longer, a call with the plain workspace returns TMP_EWIDE (nothing usable has been
  * written); a call with the wide workspace completes those rows through per-chunk prefix

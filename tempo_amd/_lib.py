@@ -47,7 +47,8 @@ class RangeStatsArgs(C.Structure):
                 ("ts_is_seconds", C.c_int32), ("x_is_i64", C.c_int32), ("x", _vp),
                 ("x_valid", _vp), ("range_back_secs", C.c_int64), ("out_perm", _vp),
                 ("out_mean", _vp), ("out_count", _vp), ("out_min", _vp), ("out_max", _vp),
-                ("out_sum", _vp), ("out_stddev", _vp), ("out_zscore", _vp), ("out_valid", _vp)]
+                ("out_sum", _vp), ("out_stddev", _vp), ("out_zscore", _vp), ("out_valid", _vp),
+                ("any_order", C.c_int32)]
 
 
 class EmaArgs(C.Structure):

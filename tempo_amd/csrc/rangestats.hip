@@ -567,6 +567,7 @@ struct RsPlan {
   uint64_t *xs;
   int32_t *deferred;
   RsWidePlan wide;
+  RsCellsPlan cells;
 };
 
 static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p, bool with_wide) {
@@ -574,19 +575,29 @@ static void rs_plan(const tmp_range_stats_args *a, Workspace &ws, RsPlan *p, boo
   p->xs = ws.take<uint64_t>((size_t)(a->n > 0 ? a->n : 1));
   p->deferred = ws.take<int32_t>(1);
   if (with_wide) rs_wide_plan(a->n, a->x_is_i64 != 0, ws, &p->wide);
+  rs_cells_plan(a, ws, &p->cells);
+}
+
+static void rs_spec(const tmp_range_stats_args *a, OrderSpec *s) {
+  memset(s, 0, sizeof(*s));
+  s->n = a->n; s->key = a->key; s->n_keys = a->n_keys; s->ts = a->ts;
+  s->prim_div = a->ts_is_seconds ? 1 : 1000000;
+  s->n_masks = 1;
+  s->masks[0] = a->x_valid;  // NULL pointer = every row valid
 }
 
 template <typename T>
-static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipStream_t st) {
+static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipStream_t st,
+                  const RangeInfo *known = nullptr) {
   OrderSpec s;
-  memset(&s, 0, sizeof(s));
-  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts;
-  s.prim_div = a->ts_is_seconds ? 1 : 1000000;
-  s.n_masks = 1;
-  s.masks[0] = a->x_valid;  // NULL pointer = every row valid
-  TMP_TRY(order_scan_ranges(s, p.ob, st));
+  rs_spec(a, &s);
   RangeInfo r;
-  TMP_TRY(order_read_ranges(p.ob, &r, st));
+  if (known) {
+    r = *known;
+  } else {
+    TMP_TRY(order_scan_ranges(s, p.ob, st));
+    TMP_TRY(order_read_ranges(p.ob, &r, st));
+  }
   Layout lay;
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   OrderResult res;
@@ -658,5 +669,17 @@ extern "C" int tmp_range_stats(const tmp_range_stats_args *a, void *workspace,
   rs_plan(a, ws, &p, have_wide);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_range_stats: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  return a->x_is_i64 ? rs_run<int64_t>(a, p, have_wide, st) : rs_run<double>(a, p, have_wide, st);
+  RangeInfo range;
+  const RangeInfo *known = nullptr;
+  if (p.cells.planned) {  // any_order: a time-ordered feed over few (key, second) cells is not ordered at all
+    OrderSpec s;
+    rs_spec(a, &s);
+    TMP_TRY(order_scan_ranges(s, p.ob, st));
+    TMP_TRY(order_read_ranges(p.ob, &range, st));
+    known = &range;
+    bool done = false;
+    TMP_TRY(rs_cells_try(a, p.cells, range, st, &done));
+    if (done) return TMP_OK;
+  }
+  return a->x_is_i64 ? rs_run<int64_t>(a, p, have_wide, st, known) : rs_run<double>(a, p, have_wide, st, known);
 }

@@ -156,4 +156,18 @@ template <typename T>
 int rs_wide_run(const uint64_t *comp, const T *xs, int64_t n, const Layout &lay, uint64_t w,
                 const RsOut<T> &o, RsWidePlan &p, hipStream_t st);
 
+// withRangeStats over (key, second) cells (rangestats_cells.hip): planned only for calls with
+// any_order set that can take it; rs_cells_try runs it when the table's ranges (as the ordering
+// step's scan read them, seconds as the primary key) allow, and says so in *done.
+struct RsCellsPlan {
+  int planned;
+  double *sum, *total, *acc, *lin;
+  uint64_t *mn, *mx;
+  uint32_t *rows, *cnt;
+  void *runs[2];  // 64-byte records per cell: [0] from the block's start, [1] to the block's end
+  int32_t *nonfinite;
+};
+void rs_cells_plan(const tmp_range_stats_args *a, Workspace &ws, RsCellsPlan *p);
+int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo &r, hipStream_t st, bool *done);
+
 }  // namespace tmp

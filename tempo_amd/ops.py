@@ -284,8 +284,10 @@ def gather(src, idx, src_valid=None, want_valid=True):
     return out, out_valid
 
 
-def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=False):
-    """withRangeStats core (python/tempo/tsdf.py:673-721).  Outputs in (key, sec) order."""
+def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=False, any_order=False):
+    """withRangeStats core (python/tempo/tsdf.py:673-721).  Outputs in (key, sec) order, out["perm"]
+    naming the input row of each; any_order=True: in whatever row order the library finds cheapest
+    (a time-ordered feed over few (key, second) cells comes back in its own order, perm = identity)."""
     n = ts.numel()
     dev = ts.device
     _dev(ts, torch.int64, "ts")
@@ -305,7 +307,7 @@ def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=Fals
     a = RangeStatsArgs(n, _p(key), int(n_keys), _p(ts), int(bool(ts_is_seconds)), int(is_i64),
                        _p(x), _p(x_valid), int(range_back_secs), _p(out["perm"]), _p(out["mean"]),
                        _p(out["count"]), _p(out["min"]), _p(out["max"]), _p(out["sum"]),
-                       _p(out["stddev"]), _p(out["zscore"]), _p(out["valid"]))
+                       _p(out["stddev"]), _p(out["zscore"]), _p(out["valid"]), int(bool(any_order)))
     ws = _workspace(lib().tmp_range_stats_workspace_bytes(C.byref(a)), dev)
     rc = lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
     if rc == _lib.TMP_EWIDE:

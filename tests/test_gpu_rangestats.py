@@ -222,3 +222,70 @@ def test_range_stats_frames_across_superblocks(ops, trend):
     m = cnt > 1
     np.testing.assert_allclose(g["stddev"][m], sd[m], rtol=RTOL, atol=1e-12 * 500)
     np.testing.assert_allclose(g["sum"], mean * cnt, rtol=1e-9)
+
+
+def _by_row(d, perm, names):
+    inv = np.empty(len(perm), np.int64)
+    inv[np.asarray(perm, np.int64)] = np.arange(len(perm))
+    return {k: np.asarray(d[k])[inv] for k in names}
+
+
+@pytest.mark.parametrize("case", ["ticks", "sparse_keys", "seconds_ts", "w0", "long_window", "single_series",
+                                  "with_nan", "random_order"])
+def test_range_stats_any_order_over_second_cells(orc, ops, case, monkeypatch):
+    """any_order: a time-ordered feed is aggregated per (key, second) cell and every row's frame
+    looked up as the union of at most two runs of cells; the rows come back where they lie.
+    Compared row by row with the oracle: counts / min / max / NULL flags exact, fp64 statistics to
+    1e-9.  NULLs, a window of 0 s, a window longer than the table, a table without keys,
+    second-valued timestamps; NaNs and a feed in random order fall back to the ordered path."""
+    monkeypatch.setenv("TEMPO_DENSE_MIN_ROWS", "1")
+    rng = np.random.default_rng(131)
+    n, nk, W = 250_000, 37, 600
+    gap = 0.05                                      # ~20 rows per second over all keys
+    if case == "long_window":
+        n = 60_000                                  # every frame will reach back to the key's first row
+    if case == "sparse_keys":
+        nk = 700                                    # ~35 seconds between two rows of a key
+    if case == "single_series":
+        nk = 1
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + (rng.exponential(gap, n).cumsum() * 1e6).astype(np.int64)
+    secs = case == "seconds_ts"
+    if secs:
+        ts = ts // 1_000_000
+    if case == "w0":
+        W = 0
+    if case == "long_window":
+        W = 10**7
+    if case == "random_order":
+        p = rng.permutation(n); key, ts = key[p], ts[p]
+    x = 100 + rng.normal(0, 1, n).cumsum() * 0.01
+    if case == "with_nan":
+        x[rng.integers(0, n, 20)] = np.nan
+    xv = (rng.random(n) >= 0.1).astype(np.uint8)
+    k_np = None if case == "single_series" else key
+    out = ops.range_stats(_dev(k_np), _dev(ts), _dev(x), _dev(xv), nk, W, ts_is_seconds=secs, any_order=True)
+    torch.cuda.synchronize()
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    perm = g["perm"].astype(np.int64)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    if case not in ("with_nan", "random_order"):
+        assert np.array_equal(perm, np.arange(n)), "the cells path leaves the rows where they lie"
+    ref = orc.range_stats(k_np, ts, x, xv, W, ts_is_seconds=secs)
+    names = ["count", "mean", "min", "max", "sum", "stddev", "zscore"]
+    G = _by_row(g, perm, names + ["valid"])
+    R = _by_row(ref, ref["perm"], names + ["stat_valid", "stddev_valid", "zscore_valid"])
+    assert np.array_equal(G["count"], R["count"])
+    sv, dv, zv = (G["valid"] & 1) != 0, (G["valid"] & 2) != 0, (G["valid"] & 4) != 0
+    assert np.array_equal(sv, R["stat_valid"].astype(bool))
+    assert np.array_equal(dv, R["stddev_valid"].astype(bool))
+    assert np.array_equal(zv, R["zscore_valid"].astype(bool))
+    assert np.array_equal(G["min"][sv], R["min"][sv], equal_nan=True)
+    assert np.array_equal(G["max"][sv], R["max"][sv], equal_nan=True)
+    np.testing.assert_allclose(G["sum"][sv], R["sum"][sv], rtol=RTOL, atol=0, equal_nan=True)
+    np.testing.assert_allclose(G["mean"][sv], R["mean"][sv], rtol=RTOL, atol=0, equal_nan=True)
+    np.testing.assert_allclose(G["stddev"][dv], R["stddev"][dv], rtol=RTOL, atol=1e-10, equal_nan=True)
+    zt = RTOL * np.maximum(1.0, np.abs(R["zscore"][zv]))
+    dz = np.abs(G["zscore"][zv] - R["zscore"][zv])
+    ok = (dz <= zt * 10) | (np.isnan(G["zscore"][zv]) & np.isnan(R["zscore"][zv]))
+    assert ok.all(), f"zscore off: max {np.nanmax(dz)}"

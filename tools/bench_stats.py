@@ -16,8 +16,11 @@ import bench  # noqa: E402
 from tempo_amd import _lib, ops  # noqa: E402
 
 
+ANY_ORDER = False
+
+
 def timed(t, reps=2):
-    f = lambda: ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], 100, 600)
+    f = lambda: ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], 100, 600, any_order=ANY_ORDER)
     f()
     torch.cuda.synchronize()
     _lib.profile_reset()
@@ -38,11 +41,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--runs", type=int, default=8)
+    ap.add_argument("--density", type=float, default=1.0, help="ticks per second and symbol (bench.py: 1)")
+    ap.add_argument("--any-order", action="store_true", help="let the library return the rows in any order")
     args = ap.parse_args()
+    global ANY_ORDER
+    ANY_ORDER = args.any_order
     dev = torch.device("cuda", 0)
     _lib.profile_enable(True)
     n = args.rows
-    tk = bench.gen_ticks(dev, n, 100, 2345)
+    tk = bench.gen_ticks(dev, n, 100, 2345, shards=1.0 / args.density)
     out = {}
     out["time_ordered"] = timed(tk)
     # N runs: rank r of N keeps every N-th block of 1/N of the rows... simplest faithful stand-in:
