@@ -119,29 +119,59 @@ __global__ __launch_bounds__(kBlock) void cell_runs_kernel(StatTab tab, int64_t 
   }
 }
 
-// Every row's frame and statistics, written where the row lies.
+// Every row's frame and statistics, written where the row lies.  Four rows per thread: their
+// inputs, then their records, are requested together before anything is computed from them.
 __global__ __launch_bounds__(kBlock) void cell_rows_kernel(const int32_t *key, const int64_t *ts, const double *x,
                                                            const uint8_t *x_valid, int64_t n, int64_t sec_div,
                                                            int64_t smin, int64_t per_key, int64_t blk, int64_t w,
                                                            RunTab pre, RunTab suf, RsOut<double> o) {
-  const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-    const int64_t t = ts[i];
-    const int64_t s = (sec_div == 1 ? t : floordiv_i64(t, sec_div)) - smin;
-    const int64_t p = s - w > 0 ? s - w : 0;
-    const int64_t base = (key ? (int64_t)key[i] : 0) * per_key;
-    const double xv = x[i];
-    const bool x_ok = !x_valid || x_valid[i];
-    RunAgg a = run_get(pre, base + s);
-    // the frame starts in the block before the row's: that block's tail joins in
-    if (floordiv_i64(p, blk) != floordiv_i64(s, blk)) a = run_merge(run_get(suf, base + p), a);
-    const int64_t cnt = a.n;
-    const double mean = cnt ? a.sum / (double)cnt : 0.0;
-    const bool sd_ok = cnt > 1;
-    const double sd = sd_ok ? sqrt(a.m2 / (double)(cnt - 1)) : 0.0;
-    o.perm[i] = (int32_t)i;
-    rs_store<double>(o, i, cnt, mean, __longlong_as_double((long long)decode_f64(a.mn)),
-                     __longlong_as_double((long long)decode_f64(a.mx)), a.sum, sd_ok, sd, x_ok, xv);
+  constexpr int U = 4;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i0 < n; i0 += step) {
+    int64_t t[U], at[U];
+    int32_t k[U];
+    double xv[U];
+    bool x_ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      at[u] = i < n ? i : n - 1;
+      t[u] = ts[at[u]];
+      k[u] = key ? key[at[u]] : 0;
+      xv[u] = x[at[u]];
+      x_ok[u] = !x_valid || x_valid[at[u]];
+    }
+    int64_t cs[U], cp[U];
+    bool two[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t s = (sec_div == 1 ? t[u] : floordiv_i64(t[u], sec_div)) - smin;
+      const int64_t p = s - w > 0 ? s - w : 0;
+      const int64_t base = (int64_t)k[u] * per_key;
+      cs[u] = base + s;
+      cp[u] = base + p;
+      // the frame starts in the block before the row's: that block's tail joins in.  (A frame is
+      // blk seconds long, so it lies in one block exactly when it starts at a multiple of blk.)
+      two[u] = p > 0 && p - floordiv_i64(p, blk) * blk != 0;
+    }
+    RunAgg a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = run_get(pre, cs[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = run_get(suf, two[u] ? cp[u] : cs[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + (int64_t)u * blockDim.x;
+      if (i >= n) continue;
+      const RunAgg f = two[u] ? run_merge(b[u], a[u]) : a[u];
+      const int64_t cnt = f.n;
+      const double mean = cnt ? f.sum / (double)cnt : 0.0;
+      const bool sd_ok = cnt > 1;
+      const double sd = sd_ok ? sqrt(f.m2 / (double)(cnt - 1)) : 0.0;
+      o.perm[i] = (int32_t)i;
+      rs_store<double>(o, i, cnt, mean, __longlong_as_double((long long)decode_f64(f.mn)),
+                       __longlong_as_double((long long)decode_f64(f.mx)), f.sum, sd_ok, sd, x_ok[u], xv[u]);
+    }
   }
 }
 
@@ -207,7 +237,7 @@ int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo 
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
   o.mn = (double *)a->out_min; o.mx = (double *)a->out_max; o.sum = (double *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
-  TMP_LAUNCH(cell_rows_kernel, dim3(grid_for(a->n, kBlock * 4, 1 << 16)), dim3(kBlock), st, a->key, a->ts,
+  TMP_LAUNCH(cell_rows_kernel, dim3(grid_for(a->n, kBlock * 4, 1 << 20)), dim3(kBlock), st, a->key, a->ts,
              (const double *)a->x, a->x_valid, a->n, sec_div, r.prim_min, (int64_t)per_key, blk, w, pre, suf, o);
   TMP_CHECK_HIP(hipGetLastError());
   *done = true;
