@@ -117,6 +117,7 @@ __global__ __launch_bounds__(DH_THREADS) void dense_stats_kernel(const int32_t *
     for (int r = 0; r < DH_ROWS; ++r) {
       if (row[r] >= n) continue;
       const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
+      if ((int64_t)g >= tab.cells || k[r] > 0xffffu) continue;  // a key id outside the dictionary: no cell
       uint32_t slot = (g * 2654435761u) >> 23;  // top 9 bits
       bool found = false;
       for (int probe = 0; probe < DH_PROBES; ++probe) {

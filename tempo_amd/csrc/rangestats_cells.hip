@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void cell_runs_kernel(StatTab tab, int64_t 
 __global__ __launch_bounds__(kBlock) void cell_rows_kernel(const int32_t *key, const int64_t *ts, const double *x,
                                                            const uint8_t *x_valid, int64_t n, int64_t sec_div,
                                                            int64_t smin, int64_t per_key, int64_t blk, int64_t w,
-                                                           RunTab pre, RunTab suf, RsOut<double> o) {
+                                                           int64_t n_keys, RunTab pre, RunTab suf, RsOut<double> o) {
   constexpr int U = 4;
   const int64_t step = (int64_t)gridDim.x * blockDim.x * U;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i0 < n; i0 += step) {
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kBlock) void cell_rows_kernel(const int32_t *key, c
       at[u] = i < n ? i : n - 1;
       t[u] = ts[at[u]];
       k[u] = key ? key[at[u]] : 0;
+      if ((uint32_t)k[u] >= (uint32_t)n_keys) k[u] = (int32_t)n_keys - 1;  // outside the dictionary: read as the last key
       xv[u] = x[at[u]];
       x_ok[u] = !x_valid || x_valid[at[u]];
     }
@@ -238,7 +239,7 @@ int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo 
   o.mn = (double *)a->out_min; o.mx = (double *)a->out_max; o.sum = (double *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
   TMP_LAUNCH(cell_rows_kernel, dim3(grid_for(a->n, kBlock * 4, 1 << 20)), dim3(kBlock), st, a->key, a->ts,
-             (const double *)a->x, a->x_valid, a->n, sec_div, r.prim_min, (int64_t)per_key, blk, w, pre, suf, o);
+             (const double *)a->x, a->x_valid, a->n, sec_div, r.prim_min, (int64_t)per_key, blk, w, nk, pre, suf, o);
   TMP_CHECK_HIP(hipGetLastError());
   *done = true;
   return TMP_OK;
