@@ -319,6 +319,9 @@ int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t workspace_b
  * which the hardware performed the adds and may differ between two runs (the count, the bucket
  * membership and the NULL flags do not).  TEMPO_NO_DENSE_MEAN=1 in the environment keeps every
  * mean on the ordered path.
+ * min / max of one or two columns take the same table (integer atomics on order-preserving codes of
+ * the values: exact; a NaN extreme comes back as the canonical quiet NaN, and of -0.0 and 0.0 the
+ * minimum is -0.0).  TEMPO_NO_DENSE_STATS=1 keeps them on the ordered path.
  */
 #define TMP_FUNC_FLOOR 0
 #define TMP_FUNC_MIN 1

@@ -789,6 +789,56 @@ __global__ __launch_bounds__(1024) void dense_emit_kernel(DenseTab tab, int n_co
   }
 }
 
+// resample(min / max) from the cells: the non-empty ones in (key, bucket) order, one block.
+__global__ __launch_bounds__(1024) void dense_extreme_emit_kernel(StatTab tab, int n_cols, ColPtrs cols, int want_max,
+                                                                  uint32_t per_key, int64_t bmin, int64_t dur,
+                                                                  int64_t cap, int32_t *out_key, int64_t *out_start,
+                                                                  double *out_f64, int64_t *out_i64,
+                                                                  uint8_t *out_valid, int64_t *out_count) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (tab.cells + 1023) / 1024;
+  const int64_t c0 = (int64_t)tid * per;
+  const int64_t c1 = c0 + per < tab.cells ? c0 + per : tab.cells;
+  uint32_t mine = 0;
+  for (int64_t g = c0; g < c1; ++g) mine += tab.rows[g] != 0;
+  uint32_t inc = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t at = inc - mine;
+  uint32_t total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) at += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0) *out_count = (int64_t)total;
+  for (int64_t g = c0; g < c1; ++g) {
+    if (tab.rows[g] == 0) continue;
+    out_key[at] = (int32_t)(g / per_key);
+    out_start[at] = (bmin + (int64_t)(g % per_key)) * dur;
+    for (int c = 0; c < n_cols; ++c) {
+      const size_t i = (size_t)c * tab.cells + g;
+      const bool have = tab.cnt[i] > 0;
+      const uint64_t code = want_max ? tab.mx[i] : tab.mn[i];
+      const int64_t w = (int64_t)c * cap + at;
+      out_valid[w] = have;
+      double f = 0.0;
+      int64_t iv = 0;
+      if (have) {
+        if (cols.is_i64[c]) iv = (int64_t)(code ^ (1ull << 63));
+        else f = __longlong_as_double((long long)decode_f64(code));
+      }
+      out_f64[w] = f;
+      out_i64[w] = iv;
+    }
+    ++at;
+  }
+}
+
 // The non-empty cells in (key, bucket) order with their statistics: one block.
 __global__ __launch_bounds__(1024) void dense_stats_emit_kernel(StatTab tab, int n_cols, ColPtrs cols, uint32_t per_key,
                                                                 int64_t bmin, int64_t dur, int64_t cap,
@@ -920,7 +970,8 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   Workspace ws(nullptr, 0);
   RbPlan p;
   const bool reduce = a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX || a->func == TMP_FUNC_MEAN;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN,
+          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX);
   return ws.off;
 }
 
@@ -946,7 +997,8 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
               "tmp_resample: column arrays missing");
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
-  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN);
+  rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN,
+          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -969,11 +1021,41 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   const uint32_t *perm = nullptr;
   RangeInfo range;
   const RangeInfo *known = nullptr;
-  if (p.d_rows) {
-    // mean over few cells: no ordering at all (the ranges are read either way)
+  if (p.st.rows) {
+    // min / max over few cells: one sweep over the rows as they lie (see dense_stats_kernel)
     TMP_TRY(order_scan_ranges(s, p.ob, st));
     TMP_TRY(order_read_ranges(p.ob, &range, st));
     known = &range;
+    const int64_t nk = plan_keys(a->key, a->n_keys);
+    const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;
+    const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DS_SLOTS / 2;
+    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+        !getenv("TEMPO_NO_DENSE_STATS")) {
+      StatTab tab = p.st;
+      tab.cells = (int64_t)((uint64_t)nk * per_key);
+      const size_t all = (size_t)tab.cells * a->n_cols;
+      TMP_CHECK_HIP(hipMemsetAsync(tab.rows, 0, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.cnt, 0, sizeof(uint32_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.sum, 0, sizeof(double) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.isum, 0, sizeof(uint64_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.mx, 0, sizeof(uint64_t) * all, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.mn, 0xff, sizeof(uint64_t) * all, st));
+      TMP_LAUNCH(dense_stats_kernel<0>, dim3(grid_for(a->n, DH_THREADS * DH_ROWS * 8, 2048)), dim3(DH_THREADS), st,
+                 a->key, a->ts, a->n, a->dur_us, range.prim_min, (uint32_t)per_key, a->n_cols, cp, tab);
+      TMP_LAUNCH(dense_extreme_emit_kernel, dim3(1), dim3(1024), st, tab, a->n_cols, cp,
+                 a->func == TMP_FUNC_MAX ? 1 : 0, (uint32_t)per_key, range.prim_min, a->dur_us, a->n, a->out_key,
+                 a->out_start, a->out_f64, a->out_i64, a->out_valid, a->out_count);
+      TMP_CHECK_HIP(hipGetLastError());
+      return TMP_OK;
+    }
+  }
+  if (p.d_rows) {
+    // mean over few cells: no ordering at all (the ranges are read either way)
+    if (!known) {
+      TMP_TRY(order_scan_ranges(s, p.ob, st));
+      TMP_TRY(order_read_ranges(p.ob, &range, st));
+      known = &range;
+    }
     const int64_t nk = plan_keys(a->key, a->n_keys);
     const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;  // buckets first .. last
     // rows that lie close together should fall into few cells (what overflows a block's table is

@@ -435,3 +435,36 @@ def test_grouped_stats_without_ordering(orc, ops, feed, dur, monkeypatch):
         scale = 1e12 if e["is_i64"][c] else 100.0
         np.testing.assert_allclose(r["stddev"][c].cpu().numpy()[ok2], e["stddev"][c][ok2], rtol=1e-9,
                                    atol=1e-12 * scale, equal_nan=True)
+
+
+@pytest.mark.parametrize("func", ["min", "max"])
+@pytest.mark.parametrize("feed", ["time_ordered", "sorted", "random_few_cells", "random_many_cells", "many_keys"])
+def test_resample_extremes_without_ordering(orc, ops, func, feed, monkeypatch):
+    """resample(min / max) of one or two columns from the table of (key, bucket) cells: extremes
+    as integer atomics on order-preserving codes, bit-exact against the oracle (doubles with NULLs
+    and infinities, an integer column)."""
+    monkeypatch.setenv("TEMPO_DENSE_MIN_ROWS", "1")
+    rng = np.random.default_rng(101)
+    n = 300_000
+    nk = {"many_keys": 700, "random_few_cells": 4}.get(feed, 9)
+    dur = 60_000_000
+    span = {"random_few_cells": 100 * dur, "many_keys": 300 * dur}.get(feed, 2000 * dur)
+    ts = -3 * dur + np.sort(rng.integers(0, span, n))
+    key = rng.integers(0, nk, n).astype(np.int32)
+    if feed == "sorted":
+        o = np.lexsort((ts, key)); key, ts = key[o], ts[o]
+    if feed.startswith("random"):
+        o = rng.permutation(n); key, ts = key[o], ts[o]
+    a = np.round(rng.normal(-1.7, 3.86, n), 2)
+    a[rng.random(n) < 0.001] = np.inf
+    a[rng.random(n) < 0.001] = -np.inf
+    b = rng.integers(-10**15, 10**15, n)
+    av = (rng.random(n) >= 0.3).astype(np.uint8)
+    bv = (rng.random(n) >= 0.9).astype(np.uint8)      # mostly NULL: some buckets have no value at all
+    r = ops.resample(_dev(key), _dev(ts), nk, dur, func, [_dev(a), _dev(b)], [_dev(av), _dev(bv)])
+    e = orc.resample(key, ts, dur, func, [a, b], [av, bv])
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["start"].cpu().numpy(), e["start"])
+    assert np.array_equal(r["valid"].cpu().numpy(), e["valid"])
+    assert np.array_equal(r["f64"].cpu().numpy(), e["f64"])
+    assert np.array_equal(r["i64"].cpu().numpy(), e["i64"])
