@@ -322,6 +322,9 @@ int tmp_lookback(const tmp_lookback_args *a, void *workspace, size_t workspace_b
  * min / max of one or two columns take the same table (integer atomics on order-preserving codes of
  * the values: exact; a NaN extreme comes back as the canonical quiet NaN, and of -0.0 and 0.0 the
  * minimum is -0.0).  TEMPO_NO_DENSE_STATS=1 keeps them on the ordered path.
+ * floor / ceil take it too (two sweeps: the cell's earliest / latest timestamp, then the row that
+ * carries it); when several rows of a cell tie on that timestamp and there are columns to compare
+ * them by, the call is redone the ordered way.  TEMPO_NO_DENSE_PICK=1 keeps the ordered path.
  */
 #define TMP_FUNC_FLOOR 0
 #define TMP_FUNC_MIN 1

@@ -28,6 +28,8 @@ ALGO = {
     "dense_mean_kernel": 4 + 8 + 3 * 8,
     # withGroupedStats(1 col) without ordering: key + ts + the metric column in, per sweep
     "dense_stats_kernel": 4 + 8 + 8,
+    # resample(floor) without ordering: key + ts in, per sweep
+    "dense_pick_kernel": 4 + 8,
     "bucket_count_kernel": 8,
     "bucket_starts_kernel": 8,
     # withGroupedStats(1 col): the metric column in sorted order

@@ -630,6 +630,10 @@ struct RbPlan {
   uint32_t *d_cnt;
   double *d_sum;
   StatTab st;  // withGroupedStats over few cells (see dense_stats_kernel); null pointers: not planned
+  // floor / ceil over few cells (dense_pick_kernel): rows, coded extreme timestamp, ties, row id, flag
+  uint32_t *k_rows, *k_ties, *k_row;
+  uint64_t *k_ext;
+  int32_t *k_tied;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -895,12 +899,144 @@ __global__ __launch_bounds__(1024) void dense_stats_emit_kernel(StatTab tab, int
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// floor / ceil without ordering the rows: the row with the earliest / latest timestamp of every
+// (key, bucket) cell.  Sweep 0 takes the extreme timestamp per cell (integer atomics on its code),
+// sweep 1 counts the rows that carry it and keeps the smallest of their row ids.  A cell in which
+// several rows tie on that timestamp needs the struct comparison of their columns: the call then
+// goes the ordered way (the caller reads the flag the emit kernel raises).
+// ------------------------------------------------------------------------------------------
+struct PickTab {
+  uint32_t *rows;  // [cells]
+  uint64_t *ext;   // [cells] coded extreme timestamp (floor: starts at all ones; ceil: at zero)
+  uint32_t *ties;  // [cells] rows carrying it
+  uint32_t *row;   // [cells] smallest row id among them (starts at all ones)
+  int32_t *tied;   // device flag: some cell has more than one such row
+  int64_t cells;
+};
+
+template <int SWEEP>
+__global__ __launch_bounds__(DH_THREADS) void dense_pick_kernel(const int32_t *key, const int64_t *ts, int64_t n,
+                                                                int64_t dur, int64_t bmin, uint32_t per_key,
+                                                                int want_last, PickTab tab) {
+  __shared__ uint32_t h_cell[DH_SLOTS];
+  __shared__ uint32_t h_a[DH_SLOTS];   // sweep 0: rows; sweep 1: ties
+  __shared__ uint32_t h_row[DH_SLOTS];
+  __shared__ uint64_t h_ext[DH_SLOTS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < DH_SLOTS; i += DH_THREADS) {
+    h_cell[i] = DH_EMPTY; h_a[i] = 0; h_row[i] = ~0u; h_ext[i] = want_last ? 0ull : ~0ull;
+  }
+  __syncthreads();
+  constexpr int kStep = DH_THREADS * DH_ROWS;
+  const int64_t steps = (n + kStep - 1) / kStep;
+  const int64_t per_block = (steps + gridDim.x - 1) / gridDim.x;
+  const int64_t s0 = (int64_t)blockIdx.x * per_block;
+  const int64_t s1 = s0 + per_block < steps ? s0 + per_block : steps;
+  for (int64_t st = s0; st < s1; ++st) {
+    int64_t row[DH_ROWS], t[DH_ROWS];
+    uint32_t k[DH_ROWS];
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      row[r] = st * kStep + r * DH_THREADS + tid;
+      const int64_t at = row[r] < n ? row[r] : n - 1;
+      t[r] = ts[at];
+      k[r] = key ? (uint32_t)key[at] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < DH_ROWS; ++r) {
+      if (row[r] >= n) continue;
+      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
+      if ((int64_t)g >= tab.cells || k[r] > 0xffffu) continue;  // a key id outside the dictionary: no cell
+      const uint64_t code = code_i64(t[r]);
+      if (SWEEP == 1 && tab.ext[g] != code) continue;
+      uint32_t slot = (g * 2654435761u) >> 22;  // top 10 bits
+      bool found = false;
+      for (int probe = 0; probe < DH_PROBES; ++probe) {
+        const uint32_t old = atomicCAS(&h_cell[slot], DH_EMPTY, g);
+        if (old == DH_EMPTY || old == g) { found = true; break; }
+        slot = (slot + 1) & (DH_SLOTS - 1);
+      }
+      if (SWEEP == 0) {
+        if (found) {
+          atomicAdd(&h_a[slot], 1u);
+          if (want_last) atomicMax((unsigned long long *)&h_ext[slot], (unsigned long long)code);
+          else atomicMin((unsigned long long *)&h_ext[slot], (unsigned long long)code);
+        } else {
+          atomicAdd(&tab.rows[g], 1u);
+          if (want_last) atomicMax((unsigned long long *)&tab.ext[g], (unsigned long long)code);
+          else atomicMin((unsigned long long *)&tab.ext[g], (unsigned long long)code);
+        }
+      } else {
+        if (found) {
+          atomicAdd(&h_a[slot], 1u);
+          atomicMin(&h_row[slot], (uint32_t)row[r]);
+        } else {
+          atomicAdd(&tab.ties[g], 1u);
+          atomicMin(&tab.row[g], (uint32_t)row[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < DH_SLOTS; i += DH_THREADS) {
+    const uint32_t g = h_cell[i];
+    if (g == DH_EMPTY || !h_a[i]) continue;
+    if (SWEEP == 0) {
+      atomicAdd(&tab.rows[g], h_a[i]);
+      if (want_last) atomicMax((unsigned long long *)&tab.ext[g], (unsigned long long)h_ext[i]);
+      else atomicMin((unsigned long long *)&tab.ext[g], (unsigned long long)h_ext[i]);
+    } else {
+      atomicAdd(&tab.ties[g], h_a[i]);
+      atomicMin(&tab.row[g], h_row[i]);
+    }
+  }
+}
+
+// The non-empty cells in (key, bucket) order with the row picked for each: one block.
+__global__ __launch_bounds__(1024) void dense_pick_emit_kernel(PickTab tab, int ties_matter, uint32_t per_key,
+                                                               int64_t bmin, int64_t dur, int32_t *out_key,
+                                                               int64_t *out_start, int32_t *out_row,
+                                                               int64_t *out_count) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (tab.cells + 1023) / 1024;
+  const int64_t c0 = (int64_t)tid * per;
+  const int64_t c1 = c0 + per < tab.cells ? c0 + per : tab.cells;
+  uint32_t mine = 0;
+  for (int64_t g = c0; g < c1; ++g) mine += tab.rows[g] != 0;
+  uint32_t inc = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t at = inc - mine;
+  uint32_t total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) at += wave_tot[w];
+    total += wave_tot[w];
+  }
+  if (tid == 0) *out_count = (int64_t)total;
+  bool tied = false;
+  for (int64_t g = c0; g < c1; ++g) {
+    if (tab.rows[g] == 0) continue;
+    out_key[at] = (int32_t)(g / per_key);
+    out_start[at] = (bmin + (int64_t)(g % per_key)) * dur;
+    out_row[at] = (int32_t)tab.row[g];
+    tied = tied || tab.ties[g] > 1;
+    ++at;
+  }
+  if (ties_matter && tied) *tab.tied = 1;
+}
+
 static bool dense_planned(int64_t n, int n_cols, int64_t n_keys, bool mean) {
   return mean && n >= dense_min_rows() && n_cols >= 1 && n_cols <= kDenseCols && n_keys <= kDenseKeys;
 }
 
 static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_keys, bool travel = false,
-                    bool mean = false, bool stats = false) {
+                    bool mean = false, bool stats = false, bool pick = false) {
   const int n_travel = (travel && n_cols >= 1 && n_cols <= kMaxPay) ? n_cols : 0;
   order_plan(n, ws, &p->ob, n_keys, n_travel);
   p->d_rows = p->d_cnt = nullptr;
@@ -909,6 +1045,16 @@ static void rb_plan(int64_t n, int n_cols, Workspace &ws, RbPlan *p, int64_t n_k
     p->d_sum = ws.take<double>((size_t)kDenseGroups * n_cols);
     p->d_rows = ws.take<uint32_t>((size_t)kDenseGroups);
     p->d_cnt = ws.take<uint32_t>((size_t)kDenseGroups * n_cols);
+  }
+  p->k_rows = p->k_ties = p->k_row = nullptr;
+  p->k_ext = nullptr;
+  p->k_tied = nullptr;
+  if (pick && n >= dense_min_rows() && n_keys <= kDenseKeys) {
+    p->k_ext = ws.take<uint64_t>((size_t)kDenseGroups);
+    p->k_rows = ws.take<uint32_t>((size_t)kDenseGroups);
+    p->k_ties = ws.take<uint32_t>((size_t)kDenseGroups);
+    p->k_row = ws.take<uint32_t>((size_t)kDenseGroups);
+    p->k_tied = ws.take<int32_t>(1);
   }
   memset(&p->st, 0, sizeof(p->st));
   if (stats && n >= dense_min_rows() && n_cols >= 1 && n_cols <= kStatCols && n_keys <= kDenseKeys) {
@@ -971,7 +1117,7 @@ extern "C" size_t tmp_resample_workspace_bytes(const tmp_resample_args *a) {
   RbPlan p;
   const bool reduce = a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX || a->func == TMP_FUNC_MEAN;
   rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN,
-          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX);
+          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX, !reduce);
   return ws.off;
 }
 
@@ -998,7 +1144,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   Workspace ws(workspace, workspace_bytes);
   RbPlan p;
   rb_plan(a->n, a->n_cols, ws, &p, plan_keys(a->key, a->n_keys), reduce, a->func == TMP_FUNC_MEAN,
-          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX);
+          a->func == TMP_FUNC_MIN || a->func == TMP_FUNC_MAX, !reduce);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_resample: workspace too small");
   OrderSpec s;
   memset(&s, 0, sizeof(s));
@@ -1021,11 +1167,49 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
   const uint32_t *perm = nullptr;
   RangeInfo range;
   const RangeInfo *known = nullptr;
-  if (p.st.rows) {
-    // min / max over few cells: one sweep over the rows as they lie (see dense_stats_kernel)
+  if (p.k_rows) {
+    // floor / ceil over few cells: two sweeps over the rows as they lie, unless rows tie on a cell's
+    // extreme timestamp (their columns then decide, which the ordered path works out)
     TMP_TRY(order_scan_ranges(s, p.ob, st));
     TMP_TRY(order_read_ranges(p.ob, &range, st));
     known = &range;
+    const int64_t nk = plan_keys(a->key, a->n_keys);
+    // floor / ceil order by ts itself: the buckets of the first and the last timestamp
+    auto fdiv = [](int64_t x, int64_t d) { int64_t q = x / d; return (x % d != 0 && x < 0) ? q - 1 : q; };  // d > 0
+    const int64_t b_lo = fdiv(range.prim_min, a->dur_us), b_hi = fdiv(range.prim_max, a->dur_us);
+    const uint64_t per_key = (uint64_t)(b_hi - b_lo) + 1;
+    const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DH_SLOTS / 2;
+    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+        !getenv("TEMPO_NO_DENSE_PICK")) {
+      PickTab tab;
+      tab.cells = (int64_t)((uint64_t)nk * per_key);
+      tab.rows = p.k_rows; tab.ext = p.k_ext; tab.ties = p.k_ties; tab.row = p.k_row; tab.tied = p.k_tied;
+      const int want_last = a->func == TMP_FUNC_CEIL ? 1 : 0;
+      TMP_CHECK_HIP(hipMemsetAsync(tab.rows, 0, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.ties, 0, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.row, 0xff, sizeof(uint32_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.ext, want_last ? 0 : 0xff, sizeof(uint64_t) * tab.cells, st));
+      TMP_CHECK_HIP(hipMemsetAsync(tab.tied, 0, sizeof(int32_t), st));
+      const int grid = grid_for(a->n, DH_THREADS * DH_ROWS * 8, 2048);
+      TMP_LAUNCH(dense_pick_kernel<0>, dim3(grid), dim3(DH_THREADS), st, a->key, a->ts, a->n, a->dur_us, b_lo,
+                 (uint32_t)per_key, want_last, tab);
+      TMP_LAUNCH(dense_pick_kernel<1>, dim3(grid), dim3(DH_THREADS), st, a->key, a->ts, a->n, a->dur_us, b_lo,
+                 (uint32_t)per_key, want_last, tab);
+      TMP_LAUNCH(dense_pick_emit_kernel, dim3(1), dim3(1024), st, tab, a->n_cols > 0 ? 1 : 0, (uint32_t)per_key, b_lo,
+                 a->dur_us, a->out_key, a->out_start, a->out_row, a->out_count);
+      int32_t tied = 0;
+      TMP_CHECK_HIP(hipMemcpyAsync(&tied, tab.tied, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      TMP_CHECK_HIP(hipStreamSynchronize(st));
+      if (!tied) return TMP_OK;
+    }
+  }
+  if (p.st.rows) {
+    // min / max over few cells: one sweep over the rows as they lie (see dense_stats_kernel)
+    if (!known) {
+      TMP_TRY(order_scan_ranges(s, p.ob, st));
+      TMP_TRY(order_read_ranges(p.ob, &range, st));
+      known = &range;
+    }
     const int64_t nk = plan_keys(a->key, a->n_keys);
     const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;
     const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DS_SLOTS / 2;

@@ -468,3 +468,34 @@ def test_resample_extremes_without_ordering(orc, ops, func, feed, monkeypatch):
     assert np.array_equal(r["valid"].cpu().numpy(), e["valid"])
     assert np.array_equal(r["f64"].cpu().numpy(), e["f64"])
     assert np.array_equal(r["i64"].cpu().numpy(), e["i64"])
+
+
+@pytest.mark.parametrize("func", ["floor", "ceil"])
+@pytest.mark.parametrize("feed", ["time_ordered", "sorted", "random_few_cells", "many_keys", "ties", "no_columns"])
+def test_resample_pick_without_ordering(orc, ops, func, feed, monkeypatch):
+    """floor / ceil from the table of (key, bucket) cells: the row with the cell's earliest /
+    latest timestamp.  Rows that tie on it are decided by their columns, which sends the call the
+    ordered way ("ties"); without columns the earliest of them in the table wins either way."""
+    monkeypatch.setenv("TEMPO_DENSE_MIN_ROWS", "1")
+    rng = np.random.default_rng(103)
+    n = 200_000
+    nk = {"many_keys": 700, "random_few_cells": 4}.get(feed, 9)
+    dur = 60_000_000
+    span = {"random_few_cells": 100 * dur, "many_keys": 300 * dur}.get(feed, 2000 * dur)
+    ts = -3 * dur + np.sort(rng.integers(0, span, n))
+    if feed in ("ties", "no_columns"):
+        ts = (ts // 1_000_000) * 1_000_000            # whole seconds: many rows share a timestamp
+    key = rng.integers(0, nk, n).astype(np.int32)
+    if feed == "sorted":
+        o = np.lexsort((ts, key)); key, ts = key[o], ts[o]
+    if feed.startswith("random"):
+        o = rng.permutation(n); key, ts = key[o], ts[o]
+    a = np.round(rng.normal(0, 2, n), 1)
+    b = rng.integers(-5, 6, n)
+    av = (rng.random(n) >= 0.2).astype(np.uint8)
+    cols, valid = ([], []) if feed == "no_columns" else ([a, b], [av, None])
+    r = ops.resample(_dev(key), _dev(ts), nk, dur, func, [_dev(x) for x in cols], [_dev(v) for v in valid])
+    e = orc.resample(key, ts, dur, func, cols, valid)
+    assert r["n"] == e["n"]
+    assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["start"].cpu().numpy(), e["start"])
+    assert np.array_equal(r["row"].cpu().numpy().astype(np.int64), e["row"])
