@@ -195,7 +195,7 @@ int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo 
   if (!p.planned || sorted_mode(r) == 0) return TMP_OK;
   const int64_t nk = plan_keys(a->key, a->n_keys);
   const uint64_t per_key = (uint64_t)r.prim_max - (uint64_t)r.prim_min + 1;  // seconds first .. last
-  if (per_key > (uint64_t)kCellMax || (uint64_t)nk * per_key > (uint64_t)kCellMax) return TMP_OK;
+  if (per_key < 1 || per_key > (uint64_t)kCellMax || (uint64_t)nk * per_key > (uint64_t)kCellMax) return TMP_OK;
   StatTab tab;
   memset(&tab, 0, sizeof(tab));
   tab.cells = (int64_t)((uint64_t)nk * per_key);

@@ -1177,9 +1177,9 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     // floor / ceil order by ts itself: the buckets of the first and the last timestamp
     auto fdiv = [](int64_t x, int64_t d) { int64_t q = x / d; return (x % d != 0 && x < 0) ? q - 1 : q; };  // d > 0
     const int64_t b_lo = fdiv(range.prim_min, a->dur_us), b_hi = fdiv(range.prim_max, a->dur_us);
-    const uint64_t per_key = (uint64_t)(b_hi - b_lo) + 1;
+    const uint64_t per_key = (uint64_t)b_hi - (uint64_t)b_lo + 1;
     const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DH_SLOTS / 2;
-    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+    if (per_key >= 1 && per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
         !getenv("TEMPO_NO_DENSE_PICK")) {
       PickTab tab;
       tab.cells = (int64_t)((uint64_t)nk * per_key);
@@ -1213,7 +1213,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     const int64_t nk = plan_keys(a->key, a->n_keys);
     const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;
     const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DS_SLOTS / 2;
-    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+    if (per_key >= 1 && per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
         !getenv("TEMPO_NO_DENSE_STATS")) {
       StatTab tab = p.st;
       tab.cells = (int64_t)((uint64_t)nk * per_key);
@@ -1246,7 +1246,7 @@ extern "C" int tmp_resample(const tmp_resample_args *a, void *workspace, size_t 
     // added to the global one row by row): a feed in some time order -- or so few cells that a
     // block's table holds them all
     const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DH_SLOTS / 2;
-    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+    if (per_key >= 1 && per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
         !getenv("TEMPO_NO_DENSE_MEAN")) {
       DenseTab tab;
       tab.cells = (int64_t)((uint64_t)nk * per_key);
@@ -1348,7 +1348,7 @@ extern "C" int tmp_grouped_stats(const tmp_grouped_stats_args *a, void *workspac
     const int64_t nk = plan_keys(a->key, a->n_keys);
     const uint64_t per_key = (uint64_t)range.prim_max - (uint64_t)range.prim_min + 1;
     const bool local = sorted_mode(range) != 0 || (uint64_t)nk * per_key <= DS_SLOTS / 2;
-    if (per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
+    if (per_key >= 1 && per_key <= (uint64_t)kDenseGroups && (uint64_t)nk * per_key <= (uint64_t)kDenseGroups && local &&
         !getenv("TEMPO_NO_DENSE_STATS")) {
       StatTab tab = p.st;
       tab.cells = (int64_t)((uint64_t)nk * per_key);
