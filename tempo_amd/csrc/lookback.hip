@@ -211,10 +211,10 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
   const uint32_t total = (uint32_t)rows * per_row;
   double *ob = out + o0 * per_row;
   uint8_t *vb = out_valid ? out_valid + o0 * per_row : nullptr;
-  auto element = [&](uint32_t q, double &val, uint8_t &ok) {
-    uint32_t rem, f;
-    const uint32_t o = div_small(q, per_row, inv_per_row, &rem);
-    const uint32_t l = div_small(rem, (uint32_t)n_feat, inv_feat, &f);
+  // element q of the block = (row o, lag l, feature f); the split is divided out once per thread
+  // and then advanced: a step moves q by a fixed amount, i.e. (o, rem) by its quotient and
+  // remainder, and q + 1 is the next feature (or lag, or row)
+  auto fetch = [&](uint32_t o, uint32_t l, uint32_t f, double &val, uint8_t &ok) {
     const int m = m_s[o];
     val = 0.0;
     ok = 0;
@@ -232,12 +232,27 @@ __global__ __launch_bounds__(LB_THREADS) void lookback_write_kernel(
   };
   // two elements per thread and step, stored as one 16-byte word where the output allows it
   const bool wide = (((uintptr_t)ob) & 15) == 0;
-  for (uint32_t q = threadIdx.x * 2; q < total; q += LB_THREADS * 2) {
+  constexpr uint32_t kStride = LB_THREADS * 2;
+  uint32_t dummy;
+  const uint32_t step_o = div_small(kStride, per_row, inv_per_row, &dummy), step_rem = dummy;
+  uint32_t rem;
+  uint32_t o = div_small(threadIdx.x * 2, per_row, inv_per_row, &rem);
+  for (uint32_t q = threadIdx.x * 2; q < total; q += kStride) {
+    uint32_t f;
+    const uint32_t l = div_small(rem, (uint32_t)n_feat, inv_feat, &f);
     double v0, v1 = 0.0;
     uint8_t k0, k1 = 0;
-    element(q, v0, k0);
+    fetch(o, l, f, v0, k0);
     const bool two = q + 1 < total;
-    if (two) element(q + 1, v1, k1);
+    if (two) {
+      uint32_t o1 = o, l1 = l, f1 = f + 1;
+      if (f1 == (uint32_t)n_feat) { f1 = 0; ++l1; }
+      if (l1 == (uint32_t)lookback) { l1 = 0; ++o1; }
+      fetch(o1, l1, f1, v1, k1);
+    }
+    o += step_o;
+    rem += step_rem;
+    if (rem >= per_row) { rem -= per_row; ++o; }
     if (two && wide) {
       *reinterpret_cast<double2 *>(ob + q) = make_double2(v0, v1);
     } else {
