@@ -1,4 +1,4 @@
-"""Secondary operators at the sizes the survey names for them (one MI355X, synthetic data
+"""Secondary operators on an accelerometer-shaped table (one MI355X, synthetic data
 resident in HBM).  Prints one JSON line per operator: rows/s, ms per call and the per-kernel
 device time from the library's own launch events.
 
