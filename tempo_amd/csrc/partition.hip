@@ -47,13 +47,18 @@ __device__ __forceinline__ uint32_t slice_owner_of(const SliceArgs &sl, uint32_t
 
 // Part of one row; `counted` = the row goes anywhere at all.  In halo mode the result is the part
 // that needs a COPY of the row, or n_parts ("none", not counted).
-__device__ __forceinline__ uint32_t route_row(uint32_t k, int64_t i, uint32_t n_parts,
-                                              const int32_t *__restrict__ table, uint32_t n_table,
-                                              const SliceArgs &sl, bool &counted) {
+// Balanced ownership: a small table, read by every row (stays in cache).  The read is
+// unconditional (keys outside the table read entry 0 and get 0), so the lookups of several rows can
+// be in flight together.
+__device__ __forceinline__ int32_t route_entry(uint32_t k, const int32_t *__restrict__ table, uint32_t n_table) {
+  const int32_t t = table[k < n_table ? k : 0u];
+  return k < n_table ? t : 0;
+}
+
+// The part a table entry stands for (see route_row).
+__device__ __forceinline__ uint32_t route_from_entry(int32_t t, int64_t i, uint32_t n_parts, const SliceArgs &sl,
+                                                     bool &counted) {
   counted = true;
-  if (!table) return mix_key(k) % n_parts;
-  // balanced ownership: a small table, read by every row (stays in cache)
-  const int32_t t = k < n_table ? table[k] : 0;
   const bool sliced = t < 0 && sl.ts && (uint32_t)(-(t + 1)) < sl.n_split;
   if (!sliced) {
     if (sl.halo) { counted = false; return n_parts; }
@@ -71,6 +76,13 @@ __device__ __forceinline__ uint32_t route_row(uint32_t k, int64_t i, uint32_t n_
   const uint32_t o2 = slice_owner_of(sl, slot, (int64_t)q + 1, n_parts);
   counted = tail && o2 != o;
   return counted ? o2 : n_parts;
+}
+
+__device__ __forceinline__ uint32_t route_row(uint32_t k, int64_t i, uint32_t n_parts,
+                                              const int32_t *__restrict__ table, uint32_t n_table,
+                                              const SliceArgs &sl, bool &counted) {
+  if (!table) { counted = true; return mix_key(k) % n_parts; }
+  return route_from_entry(route_entry(k, table, n_table), i, n_parts, sl, counted);
 }
 
 // Owner of every row (the digit of the bucketing pass) and the rows per owner.
@@ -116,7 +128,22 @@ __global__ __launch_bounds__(kBlock) void owner_kernel(const int32_t *key, int64
 // Every wave owns a contiguous range of rows.  Pass 1 notes each row's part in a byte and counts
 // the wave's rows per part; an exclusive scan over [part][wave] turns the counts into where each
 // wave's rows of each part start in the bucketed order; pass 2 walks the same ranges and copies
-// every column's value straight to its place -- no row ids, no sort passes, no barriers.
+// every column's value to its place (grouped by part in a strip of LDS per wave first) -- no row
+// ids, no sort passes, no barriers.
+// Rows per lane and step, most waves, waves per SIMD.  Measured on 5x10^8 rows of (key, ts, fp64)
+// with 10^4 random keys hashed to 8 parts, count + move (tools/bench_route.py): 8.4 ms with 8192
+// waves, keys and table entries waited for row group by row group and every column stored
+// straight from the lanes that read it; 7.8 ms as it stands (16384 waves, a step's keys requested
+// a step ahead, rows grouped by part in LDS before they are stored).  One part: 5.4 -> 4.8 ms.
+#ifndef TEMPO_RM_U
+#define TEMPO_RM_U 4
+#endif
+#ifndef TEMPO_RM_WAVES
+#define TEMPO_RM_WAVES 16384
+#endif
+#ifndef TEMPO_RM_OCC
+#define TEMPO_RM_OCC 8
+#endif
 constexpr int kMoveWavesPerBlock = kBlock / 64;
 constexpr uint8_t kNoPart = 255;
 
@@ -129,7 +156,7 @@ struct MoveGeom {
 static MoveGeom move_geom(int64_t n) {
   MoveGeom g;
   int64_t want = (n + 64 * 64 - 1) / (64 * 64);  // at least 64 steps per wave when there is work
-  g.waves = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+  g.waves = (int)(want < 1 ? 1 : (want > TEMPO_RM_WAVES ? TEMPO_RM_WAVES : want));
   g.waves = (g.waves + kMoveWavesPerBlock - 1) / kMoveWavesPerBlock * kMoveWavesPerBlock;
   g.grid = g.waves / kMoveWavesPerBlock;
   int64_t per = (n + g.waves - 1) / g.waves;
@@ -138,7 +165,7 @@ static MoveGeom move_geom(int64_t n) {
   return g;
 }
 
-__global__ __launch_bounds__(kBlock) void route_count_kernel(const int32_t *key, int64_t n, uint32_t n_parts,
+__global__ __launch_bounds__(kBlock, 8) void route_count_kernel(const int32_t *key, int64_t n, uint32_t n_parts,
                                                              const int32_t *__restrict__ table,
                                                              uint32_t n_table, SliceArgs sl,
                                                              int64_t rows_per_wave, int n_waves,
@@ -149,28 +176,58 @@ __global__ __launch_bounds__(kBlock) void route_count_kernel(const int32_t *key,
   const int64_t lo = (int64_t)wave * rows_per_wave;
   const int64_t hi = lo + rows_per_wave < n ? lo + rows_per_wave : n;
   uint32_t mine = 0;  // lane p: rows of part p in this wave's range
-  constexpr int U = 4;  // rows per lane and step: the key loads of a step are issued together
+  // Eight rows per lane and step.  A step's keys are requested while the step before is being
+  // worked on and its table lookups are issued together: a wave otherwise waits out one memory
+  // round trip per row group for the key and another for the table entry.
+  constexpr int U = 8;
+  uint32_t k[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) k[u] = 0;
+  if (lo < hi) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = lo + u * 64 + lane;
+      k[u] = (uint32_t)key[i < hi ? i : hi - 1];
+    }
+  }
   for (int64_t base = lo; base < hi; base += 64 * U) {
-    uint32_t k[U];
+    uint32_t kn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kn[u] = 0;
+    const int64_t nb = base + 64 * U;
+    if (nb < hi) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = nb + u * 64 + lane;
+        kn[u] = (uint32_t)key[i < hi ? i : hi - 1];
+      }
+    }
+    int32_t t[U];
+    if (table) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) t[u] = route_entry(k[u], table, n_table);
+    }
+    uint32_t o[U];
+    bool counted[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = base + u * 64 + lane;
-      k[u] = i < hi ? (uint32_t)key[i] : 0u;
+      const bool in = i < hi;
+      bool c = true;
+      o[u] = table ? route_from_entry(t[u], in ? i : hi - 1, n_parts, sl, c) : mix_key(k[u]) % n_parts;
+      counted[u] = c && in;
+      if (!counted[u]) o[u] = n_parts;
+      if (in) part_of[i] = counted[u] ? (uint8_t)o[u] : kNoPart;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t i = base + u * 64 + lane;
-      bool counted = false;
-      uint32_t o = n_parts;
-      if (i < hi) {
-        o = route_row(k[u], i, n_parts, table, n_table, sl, counted);
-        part_of[i] = counted ? (uint8_t)o : kNoPart;
-      }
       for (uint32_t p = 0; p < n_parts; ++p) {
-        const uint64_t b = __ballot(counted && o == p);
+        const uint64_t b = __ballot(o[u] == p);
         if ((uint32_t)lane == p) mine += (uint32_t)__popcll(b);
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) k[u] = kn[u];
   }
   if ((uint32_t)lane < n_parts) counts[(size_t)lane * n_waves + wave] = mine;
 }
@@ -191,63 +248,106 @@ struct MoveCols {
   int bytes[kMoveCols];
 };
 
-__global__ __launch_bounds__(kBlock) void route_move_kernel(int64_t n, uint32_t n_parts, int64_t rows_per_wave,
+__global__ __launch_bounds__(kBlock, TEMPO_RM_OCC) void route_move_kernel(int64_t n, uint32_t n_parts, int64_t rows_per_wave,
                                                             int n_waves, const uint8_t *__restrict__ part_of,
                                                             const uint32_t *__restrict__ offsets,
                                                             MoveCols mc) {
+  // Four rows per lane and step.  A step's rows leave grouped by part: every wave has a strip of
+  // LDS of its own in which the step's values are put in (part, row) order, so that neighbouring
+  // lanes store to neighbouring places -- runs of rows per part instead of a few rows per part
+  // and store instruction.  LDS keeps one wave's accesses in order, so no barrier is involved.
+  constexpr int U = TEMPO_RM_U;
+  constexpr int kStep = 64 * U;
+  __shared__ uint64_t val_s[kMoveWavesPerBlock][kStep];
+  __shared__ uint32_t to_s[kMoveWavesPerBlock][kStep];
   const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * kMoveWavesPerBlock + (threadIdx.x >> 6);
+  const int wib = threadIdx.x >> 6;
+  const int wave = blockIdx.x * kMoveWavesPerBlock + wib;
+  uint64_t *val = val_s[wib];
+  uint32_t *to = to_s[wib];
   const int64_t lo = (int64_t)wave * rows_per_wave;
   const int64_t hi = lo + rows_per_wave < n ? lo + rows_per_wave : n;
   // lane p: where this wave's next row of part p goes
   uint32_t run = (uint32_t)lane < n_parts ? offsets[(size_t)lane * n_waves + wave] : 0u;
   const uint64_t below = (1ull << lane) - 1;
-  constexpr int U = 4;  // rows per lane and step
-  for (int64_t base = lo; base < hi; base += 64 * U) {
-    uint32_t o[U], dest[U];
+  uint32_t o[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = lo + u * 64 + lane;
+    o[u] = i < hi ? part_of[i] : kNoPart;
+  }
+  // one column's values of this step's rows (rows that go nowhere are not read)
+  auto fetch = [&](int c, int64_t base, uint64_t(&v)[U]) {
+    const void *src = mc.src[c];
+    const int bytes = mc.bytes[c];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      v[u] = 0;
+      if (o[u] == kNoPart) continue;
       const int64_t i = base + u * 64 + lane;
-      o[u] = i < hi ? part_of[i] : kNoPart;
+      if (bytes == 8) v[u] = ((const uint64_t *)src)[i];
+      else if (bytes == 4) v[u] = ((const uint32_t *)src)[i];
+      else v[u] = ((const uint8_t *)src)[i];
     }
+  };
+  for (int64_t base = lo; base < hi; base += kStep) {
+    uint32_t on[U], pos[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      dest[u] = 0;
-      for (uint32_t p = 0; p < n_parts; ++p) {
+    for (int u = 0; u < U; ++u) {  // the next step's parts, requested now
+      const int64_t i = base + kStep + u * 64 + lane;
+      on[u] = i < hi ? part_of[i] : kNoPart;
+    }
+    uint64_t v[U];
+    if (mc.n > 0) fetch(0, base, v);
+    // place of every row: in the bucketed order (through the strip) and inside the strip
+    uint32_t moved = 0;  // rows of this step placed so far (the same in every lane)
+#pragma unroll
+    for (int u = 0; u < U; ++u) pos[u] = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+      uint32_t start = __shfl(run, (int)p);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         const uint64_t b = __ballot(o[u] == p);
-        const uint32_t start = __shfl(run, (int)p);
-        if (o[u] == p) dest[u] = start + (uint32_t)__popcll(b & below);
-        if ((uint32_t)lane == p) run += (uint32_t)__popcll(b);
+        const uint32_t before = (uint32_t)__popcll(b & below);
+        if (o[u] == p) {
+          pos[u] = moved + before;
+          to[moved + before] = start + before;
+        }
+        const uint32_t c = (uint32_t)__popcll(b);
+        start += c;
+        moved += c;
       }
+      if ((uint32_t)lane == p) run = start;
     }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t dest[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dest[u] = (uint32_t)(u * 64 + lane) < moved ? to[u * 64 + lane] : 0u;
     for (int c = 0; c < mc.n; ++c) {
+      uint64_t vn[U];
+      if (c + 1 < mc.n) fetch(c + 1, base, vn);  // the next column is on its way while this one leaves
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (o[u] != kNoPart) val[pos[u]] = v[u];
+      __builtin_amdgcn_wave_barrier();
+      void *dst = mc.dst[c];
       const int bytes = mc.bytes[c];
-      if (bytes == 8) {
-        uint64_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) v[u] = ((const uint64_t *)mc.src[c])[base + u * 64 + lane];
+      for (int u = 0; u < U; ++u) {
+        if ((uint32_t)(u * 64 + lane) >= moved) continue;
+        const uint64_t w = val[u * 64 + lane];
+        if (bytes == 8) ((uint64_t *)dst)[dest[u]] = w;
+        else if (bytes == 4) ((uint32_t *)dst)[dest[u]] = (uint32_t)w;
+        else ((uint8_t *)dst)[dest[u]] = (uint8_t)w;
+      }
+      if (c + 1 < mc.n) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) ((uint64_t *)mc.dst[c])[dest[u]] = v[u];
-      } else if (bytes == 4) {
-        uint32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) v[u] = ((const uint32_t *)mc.src[c])[base + u * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) ((uint32_t *)mc.dst[c])[dest[u]] = v[u];
-      } else {
-        uint8_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) v[u] = ((const uint8_t *)mc.src[c])[base + u * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (o[u] != kNoPart) ((uint8_t *)mc.dst[c])[dest[u]] = v[u];
+        for (int u = 0; u < U; ++u) v[u] = vn[u];
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) o[u] = on[u];
   }
 }
 

@@ -116,12 +116,17 @@ def balanced_owners(keys, n_keys, group=None, stride=16, counts_fn=None, skew=No
     if skew is not None and world > 1 and len(hot_keys(counts, world)):
         if isinstance(ts, torch.Tensor):
             ts = [ts]
+        # (min, -max) over the time columns: one sweep per column, reduced over the ranks on the
+        # device, read by the host once
         big = torch.iinfo(torch.int64).max
-        lo = min([int(t.min()) for t in ts if t.numel()] or [big])
-        hi = max([int(t.max()) for t in ts if t.numel()] or [-big])
-        ends = torch.tensor([lo, -hi], dtype=torch.int64, device=dev)
+        ends = torch.full((2,), big, dtype=torch.int64, device=dev)
+        for t in ts:
+            if t.numel():
+                mn, mx = torch.aminmax(t)
+                ends = torch.minimum(ends, torch.stack([mn, -mx]))
         all_reduce(ends, dist.ReduceOp.MIN, group)
-        ts_range = (int(ends[0]), -int(ends[1]))
+        lo, neg_hi = ends.cpu().tolist()
+        ts_range = (int(lo), -int(neg_hi))
     return plan_owners(counts, world, dev, skew, ts_range)
 
 
