@@ -407,6 +407,9 @@ def main():
                     per_op[name] = dict(bytes=nbytes, ms=round(ms, 3),
                                         frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             roofline["ops"] = per_op
+            # launches the library's event pool could not hold (0 unless --steps is very large);
+            # per-kernel figures would then cover only the recorded ones
+            roofline["launches_not_recorded"] = _lib.profile_dropped()
         top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])[:8]
         line = {
             "metric": "AS-OF join + withRangeStats rows/sec at 1B rows (1-8 GPU); % HBM peak",

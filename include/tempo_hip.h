@@ -668,11 +668,15 @@ int tmp_arrow_import(const struct ArrowArray *array, const struct ArrowSchema *s
  * timings through its UI).  While enabled, every kernel launch of the entry points above is
  * bracketed by two HIP events on its launch stream.  tmp_profile_enable(1) creates the event
  * pool the first time (the only call here that creates HIP objects); tmp_profile_get needs the
- * stream to have been synchronised.  Not thread-safe; at most 8192 launches between resets.
+ * stream to have been synchronised.  Operators may be called from several host threads while
+ * it is enabled (launch slots come from an atomic counter); enable / reset / count / get are for
+ * one thread while no operator call is in flight.  At most 8192 launches are recorded between
+ * resets; tmp_profile_dropped() says how many more were launched and not recorded.
  */
 int tmp_profile_enable(int on);
 int tmp_profile_reset(void);
 int tmp_profile_count(void);
+int tmp_profile_dropped(void);
 int tmp_profile_get(int i, const char **kernel_name, float *ms);
 /* A caller-chosen tag stamped on every launch recorded from now on (e.g. which call it belongs to). */
 int tmp_profile_set_tag(int tag);

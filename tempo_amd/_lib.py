@@ -178,6 +178,7 @@ SYMBOLS = {
     "tmp_profile_enable": (C.c_int, [C.c_int]),
     "tmp_profile_reset": (C.c_int, []),
     "tmp_profile_count": (C.c_int, []),
+    "tmp_profile_dropped": (C.c_int, []),
     "tmp_profile_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "tmp_profile_set_tag": (C.c_int, [C.c_int]),
     "tmp_profile_tag": (C.c_int, [C.c_int]),
@@ -239,6 +240,11 @@ def profile_reset():
 
 def profile_tag(tag):
     lib().tmp_profile_set_tag(int(tag))
+
+
+def profile_dropped():
+    """Launches since the last reset that found the event pool full and were not recorded."""
+    return int(lib().tmp_profile_dropped())
 
 
 def profile_read():

@@ -1,6 +1,7 @@
 // Ordering step shared by every op: (key, primary[, seq]) -> 64-bit sort word -> stable LSD
 // radix sort of (sort word, row id) pairs.  Replaces Spark's Exchange + SortExec in front of
 // WindowExec / aggregates (python/tempo/tsdf.py:117-121, :563-572; resample.py:63).
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,18 +19,23 @@ void set_error(const char *fmt, ...) {
 }
 void clear_error() { g_err[0] = 0; }
 
-// ---- per-kernel event timing (diagnostic; not thread-safe, one device at a time)
+// ---- per-kernel event timing (diagnostic; one device at a time).  Launch slots are handed out
+//      by an atomic counter, so operators called from several host threads each keep their own
+//      slots; launches beyond the pool are counted, not recorded.  Enable / reset / read-out are
+//      for one thread while no operator call is in flight.
 constexpr int kProfSlots = 8192;
-static bool g_prof_on = false;
-static int g_prof_n = 0;
+static std::atomic<bool> g_prof_on{false};
+static std::atomic<int> g_prof_n{0};        // slots handed out (may run past kProfSlots)
 static hipEvent_t *g_prof_ev = nullptr;  // 2 * kProfSlots events, created on first enable
 static const char *g_prof_name[kProfSlots];
 static int g_prof_tag[kProfSlots];
 static int g_prof_cur_tag = 0;
 
 ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), st(s) {
-  if (!g_prof_on || g_prof_n >= kProfSlots) return;
-  slot = g_prof_n++;
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  const int got = g_prof_n.fetch_add(1, std::memory_order_relaxed);
+  if (got >= kProfSlots) return;  // pool exhausted: tmp_profile_dropped() reports how many
+  slot = got;
   g_prof_name[slot] = name;
   g_prof_tag[slot] = g_prof_cur_tag;
   (void)hipEventRecord(g_prof_ev[2 * slot], st);
@@ -2222,13 +2228,18 @@ extern "C" int tmp_profile_enable(int on) {
   g_prof_on = on != 0;
   return TMP_OK;
 }
+static int prof_recorded() {
+  const int n = g_prof_n.load(std::memory_order_relaxed);
+  return n < kProfSlots ? n : kProfSlots;
+}
 extern "C" int tmp_profile_reset(void) { g_prof_n = 0; return TMP_OK; }
-extern "C" int tmp_profile_count(void) { return g_prof_n; }
+extern "C" int tmp_profile_count(void) { return prof_recorded(); }
+extern "C" int tmp_profile_dropped(void) { return g_prof_n.load(std::memory_order_relaxed) - prof_recorded(); }
 extern "C" int tmp_profile_set_tag(int tag) { g_prof_cur_tag = tag; return TMP_OK; }
-extern "C" int tmp_profile_tag(int i) { return (i >= 0 && i < g_prof_n) ? g_prof_tag[i] : -1; }
+extern "C" int tmp_profile_tag(int i) { return (i >= 0 && i < prof_recorded()) ? g_prof_tag[i] : -1; }
 extern "C" int tmp_profile_get(int i, const char **name, float *ms) {
   clear_error();
-  TMP_REQUIRE(i >= 0 && i < g_prof_n && name && ms, TMP_EINVAL, "tmp_profile_get: bad index");
+  TMP_REQUIRE(i >= 0 && i < prof_recorded() && name && ms, TMP_EINVAL, "tmp_profile_get: bad index");
   *name = g_prof_name[i];
   TMP_CHECK_HIP(hipEventElapsedTime(ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
   return TMP_OK;

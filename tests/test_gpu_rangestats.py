@@ -289,3 +289,51 @@ def test_range_stats_any_order_over_second_cells(orc, ops, case, monkeypatch):
     dz = np.abs(G["zscore"][zv] - R["zscore"][zv])
     ok = (dz <= zt * 10) | (np.isnan(G["zscore"][zv]) & np.isnan(R["zscore"][zv]))
     assert ok.all(), f"zscore off: max {np.nanmax(dz)}"
+
+
+def test_profile_slots_from_several_host_threads(ops):
+    """Launch slots of the per-kernel event timing come from an atomic counter: four host threads
+    running the operator on streams of their own each get their launches recorded once, the
+    results are those of a single-threaded call, and nothing is reported as dropped."""
+    import threading
+    from tempo_amd import _lib
+    rng = np.random.default_rng(11)
+    n = 50_000
+    key = rng.integers(0, 8, n).astype(np.int32)
+    ts = BASE + np.sort(rng.integers(0, 600_000_000, n))
+    x = rng.normal(0, 1, n)
+    dk, dt, dx = _dev(key), _dev(ts), _dev(x)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    want = ops.range_stats(dk, dt, dx, None, 8, 30)
+    torch.cuda.synchronize()
+    per_call = len(_lib.profile_read())
+    assert per_call > 0
+    _lib.profile_reset()
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(5):
+                    got[i] = ops.range_stats(dk, dt, dx, None, 8, 30)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    recs = _lib.profile_read()
+    dropped = _lib.profile_dropped()
+    _lib.profile_enable(False)
+    _lib.profile_reset()
+    assert not errs, errs
+    assert len(recs) == 4 * 5 * per_call and dropped == 0
+    assert all(ms >= 0.0 for _, _, ms in recs)
+    for g in got:
+        for name in ("perm", "count", "min", "max", "mean", "stddev"):
+            assert torch.equal(g[name], want[name]), name
