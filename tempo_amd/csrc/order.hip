@@ -1988,6 +1988,16 @@ static bool bucketed_wanted(const OrderSpec &s, const Layout &lay, int sorted, c
   return passes_for(lay.total_bits() - lay.low_bits) >= passes_for(g->bits) + 2;
 }
 
+// out[c][j] = src[c][perm[j]]: payload columns for an order that was not produced by a radix pass
+// (a pass would have delivered them).
+__global__ __launch_bounds__(kBlock) void pay_gather_kernel(int64_t n, const uint32_t *perm, PayPtrs pp) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    const uint32_t r = perm[j];
+    for (int c = 0; c < pp.n; ++c) pp.out[c][j] = pp.src[c][r];
+  }
+}
+
 int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers &b,
                 OrderResult *res, hipStream_t st, int n_pay, const uint64_t *const *pay_src,
                 uint64_t *const *pay_out, bool *carried) {
@@ -2038,6 +2048,15 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     if (lay.key_shift() >= hi_bit) {  // no key: the merged order is the result
       res->comp = b.comp[1];
       res->perm = b.idx[1];
+      if (n_pay > 0) {  // no pass follows that would bring the payload columns along: fetch them
+        PayPtrs pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.n = n_pay;
+        for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
+        TMP_LAUNCH(pay_gather_kernel, dim3(grid_for(s.n, kBlock * 4, 8192)), dim3(kBlock), st, s.n, res->perm, pp);
+        TMP_CHECK_HIP(hipGetLastError());
+        if (carried) *carried = true;
+      }
       return TMP_OK;
     }
     return radix_passes(b, s.n, lay.key_shift(), hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr, nullptr,

@@ -75,8 +75,10 @@ void rs_wide_plan(int64_t n, bool is_i64, Workspace &ws, RsWidePlan *p) {
   p->tab_mx = ws.take<uint64_t>(nc * (size_t)levels);
 }
 
-// pivot[s] = the first finite non-NULL value in the first chunk of superblock s (0 if none):
-// one wave per superblock.
+// pivot[s] = the first finite non-NULL value of superblock s (0 if it holds none, and then no
+// value of it is ever added up): one wave per superblock.  The search goes on past the first
+// chunk: after a long run of NULLs a pivot of 0 would leave sums of squares of the values
+// themselves, and with them the variance of values far from 0, to cancellation.
 template <typename T>
 __global__ __launch_bounds__(256) void wide_pivot_kernel(const uint64_t *comp, const T *xs, int64_t n,
                                                          int64_t supers, double *pivot) {
@@ -86,8 +88,9 @@ __global__ __launch_bounds__(256) void wide_pivot_kernel(const uint64_t *comp, c
   int64_t base = s * (int64_t)WK_SUPER * WK_CHUNK;
   double pv = 0.0;
   bool found = false;
-  for (int r = 0; r < WK_CHUNK / 64 && !found; ++r) {
-    int64_t i = base + r * 64 + lane;
+  for (int r = 0; r < WK_SUPER * WK_CHUNK / 64 && !found; ++r) {
+    int64_t i = base + (int64_t)r * 64 + lane;
+    if (base + (int64_t)r * 64 >= n) break;
     bool ok = false;
     T v = (T)0;
     if (i < n && (comp[i] & 1ull)) {
@@ -220,20 +223,23 @@ __global__ __launch_bounds__(256) void wide_table_kernel(uint64_t *tab_mn, uint6
   }
 }
 
-// One piece of a frame into the running (count, mean, M2): the pairwise variance update.
+// One piece of a frame into the running (count, mean, M2): the pairwise variance update.  The
+// running mean is kept as an offset from the first piece's pivot (`ref`): the difference of two
+// pieces' means is then formed from small numbers (pivots of neighbouring superblocks subtract
+// without rounding), not from two means that each carry the rounding of the values' own level.
 __device__ __forceinline__ void piece_merge(double n_p, double s_p, double q_p, double pivot_p, double &N,
-                                            double &mean, double &M2, double &sum) {
+                                            double &ref, double &rmean, double &M2, double &sum) {
   if (n_p <= 0.0) return;
-  const double mean_p = pivot_p + s_p / n_p;
   double m2_p = q_p - s_p * s_p / n_p;
   if (m2_p < 0.0) m2_p = 0.0;
   sum += n_p * pivot_p + s_p;
   if (N == 0.0) {
-    N = n_p; mean = mean_p; M2 = m2_p;
+    N = n_p; ref = pivot_p; rmean = s_p / n_p; M2 = m2_p;
     return;
   }
-  const double delta = mean_p - mean, nn = N + n_p;
-  mean += delta * (n_p / nn);
+  const double mean_p = (pivot_p - ref) + s_p / n_p;
+  const double delta = mean_p - rmean, nn = N + n_p;
+  rmean += delta * (n_p / nn);
   M2 += m2_p + delta * delta * (N * n_p / nn);
   N = nn;
 }
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     const int64_t B = upper_bound_k(comp, i, n, k, low) - 1;
     const int64_t cA = A / WK_CHUNK, cB = B / WK_CHUNK;
     const bool a_first = (A % WK_CHUNK) == 0;
-    double N = 0.0, mean = 0.0, M2 = 0.0, dsum = 0.0;
+    double N = 0.0, ref = 0.0, rmean = 0.0, M2 = 0.0, dsum = 0.0;
     uint64_t cnt = 0, nonfin = 0, isum = 0;
     T mn = W::ident_min(), mx = W::ident_max();
     // everything of chunk c up to and including row r, minus everything before row `from`
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
       const double s = p.ps[B] - (a_first ? 0.0 : p.ps[A - 1]);
       const double q = p.pq[B] - (a_first ? 0.0 : p.pq[A - 1]);
       if (W::kInt) isum = p.pi[B] - (a_first ? 0ull : p.pi[A - 1]);
-      piece_merge((double)(cnt - nonfin), s, q, p.pivot[cA / WK_SUPER], N, mean, M2, dsum);
+      piece_merge((double)(cnt - nonfin), s, q, p.pivot[cA / WK_SUPER], N, ref, rmean, M2, dsum);
       if (!nonfin)
         for (int64_t j = A; j <= B; ++j)
           if (comp[j] & 1ull) { T v = xs[j]; mn = W::mn(mn, v); mx = W::mx(mx, v); }
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
         cnt += hv; nonfin += hn;
         if (W::kInt) isum += p.tot_i[cA] - (a_first ? 0ull : p.pi[A - 1]);
         piece_merge((double)(hv - hn), p.tot_s[cA] - (a_first ? 0.0 : p.ps[A - 1]),
-                    p.tot_q[cA] - (a_first ? 0.0 : p.pq[A - 1]), p.pivot[cA / WK_SUPER], N, mean, M2, dsum);
+                    p.tot_q[cA] - (a_first ? 0.0 : p.pq[A - 1]), p.pivot[cA / WK_SUPER], N, ref, rmean, M2, dsum);
         mn = W::mn(mn, W::val(p.smn[A]));
         mx = W::mx(mx, W::val(p.smx[A]));
       }
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
           cnt += pv; nonfin += pn;
           if (W::kInt) isum += p.exc_i[hi] + p.tot_i[hi] - p.exc_i[lo];
           piece_merge((double)(pv - pn), p.exc_s[hi] + p.tot_s[hi] - p.exc_s[lo],
-                      p.exc_q[hi] + p.tot_q[hi] - p.exc_q[lo], p.pivot[s], N, mean, M2, dsum);
+                      p.exc_q[hi] + p.tot_q[hi] - p.exc_q[lo], p.pivot[s], N, ref, rmean, M2, dsum);
         }
         const int lv = 63 - __clzll((long long)(m1 - m0 + 1));
         const uint64_t *tm = p.tab_mn + (size_t)lv * p.chunks, *tx = p.tab_mx + (size_t)lv * p.chunks;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
         const uint64_t tv = c1 & 0xffffu, tn = c1 >> 16;
         cnt += tv; nonfin += tn;
         if (W::kInt) isum += p.pi[B];
-        piece_merge((double)(tv - tn), p.ps[B], p.pq[B], p.pivot[cB / WK_SUPER], N, mean, M2, dsum);
+        piece_merge((double)(tv - tn), p.ps[B], p.pq[B], p.pivot[cB / WK_SUPER], N, ref, rmean, M2, dsum);
         mn = W::mn(mn, W::val(p.pmn[B]));
         mx = W::mx(mx, W::val(p.pmx[B]));
       }
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     const bool x_ok = (wi & 1ull) != 0;
     const bool same = cnt > 1 && mn == mx;  // all values identical: Spark's m2 is exactly 0
     const double sd = cnt > 1 ? (same ? 0.0 : sqrt(M2 / (N - 1.0))) : 0.0;
-    rs_store<T>(o, i, (int64_t)cnt, cnt ? mean : 0.0, mn, mx, sum, cnt > 1, sd, x_ok, x_ok ? (double)xs[i] : 0.0);
+    rs_store<T>(o, i, (int64_t)cnt, cnt ? ref + rmean : 0.0, mn, mx, sum, cnt > 1, sd, x_ok, x_ok ? (double)xs[i] : 0.0);
   }
 }
 

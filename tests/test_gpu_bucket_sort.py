@@ -202,3 +202,60 @@ def test_key_order_guess_wrong_falls_back(orc, monkeypatch):
     perm, ema = ops.ema(d(key), d(ts), d(x), None, 9, window=5, exp_factor=0.3)
     operm, oema = orc.ema(key, ts, x, None, 5, 0.3)
     assert np.array_equal(perm.cpu().numpy(), operm) and np.array_equal(ema.cpu().numpy(), oema)
+
+
+def test_time_ordered_runs_of_a_single_series_with_travelling_columns(orc, monkeypatch):
+    """One series (no key bits) in a few time-ordered runs: after the run merge no key pass follows
+    that would bring the operators' columns along, so they are fetched through the merged order.
+    withRangeStats (double and integer metric), EMA, resample of two columns, lookback features and
+    the fused join's left payload against the oracle."""
+    from tempo_amd import _lib, ops
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(4242)
+    n, n_runs = 90_000, 5
+    key, ts = _runs_table(rng, n, n_runs, 1, 40_000 * 1_000_000, 250_000)
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    x = 100 + np.cumsum(rng.normal(0, 1, n)) * 0.01
+    xi = rng.integers(-10**9, 10**9, n)
+    xv = (rng.random(n) >= 0.1).astype(np.uint8)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    out = ops.range_stats(None, d(ts), d(x), d(xv), 1, 5)
+    torch.cuda.synchronize()
+    names = {nm for nm, _, _ in _lib.profile_read()}
+    _lib.profile_enable(False)
+    assert "tile_merge_kernel" in names, sorted(names)
+    ref = orc.range_stats(key, ts, x, xv, 5)
+    assert np.array_equal(out["perm"].cpu().numpy(), ref["perm"]) and np.array_equal(out["count"].cpu().numpy(), ref["count"])
+    ok = ref["count"] > 0
+    assert np.array_equal(out["min"].cpu().numpy()[ok], ref["min"][ok]) and np.array_equal(out["max"].cpu().numpy()[ok], ref["max"][ok])
+    np.testing.assert_allclose(out["mean"].cpu().numpy()[ok], ref["mean"][ok], rtol=1e-9)
+    out = ops.range_stats(d(key), d(ts), d(xi), None, 1, 5)
+    ref = orc.range_stats(key, ts, xi, None, 5)
+    for name in ("perm", "count", "min", "max", "sum"):
+        assert np.array_equal(out[name].cpu().numpy(), ref[name]), name
+    perm, ema = ops.ema(None, d(ts), d(x), d(xv), 1, window=9, exp_factor=0.25)
+    operm, oema = orc.ema(key, ts, x, xv, 9, 0.25)
+    assert np.array_equal(perm.cpu().numpy(), operm) and np.array_equal(ema.cpu().numpy(), oema)
+    r = ops.resample(None, d(ts), 1, 60_000_000, "min", [d(x), d(xi)], [d(xv), None])
+    o = orc.resample(key, ts, 60_000_000, "min", [x, xi], [xv, None])
+    assert r["n"] == o["n"] and np.array_equal(r["start"].cpu().numpy(), o["start"])
+    assert np.array_equal(r["valid"].cpu().numpy(), o["valid"])
+    assert np.array_equal(r["f64"].cpu().numpy(), o["f64"]) and np.array_equal(r["i64"].cpu().numpy(), o["i64"])
+    rows, lens, feat, fv = ops.lookback(None, d(ts), [d(x), d(xi.astype(np.float64))], [d(xv), None], 1, 4, exact_size=False)
+    operm, olen, ofeat, ofv = orc.lookback(key, ts, [x, xi.astype(np.float64)], [xv, None], 4)
+    assert np.array_equal(rows.cpu().numpy().astype(np.int64), operm) and np.array_equal(lens.cpu().numpy(), olen)
+    assert np.array_equal(feat.cpu().numpy(), ofeat) and np.array_equal(fv.cpu().numpy(), ofv)
+    # fused join: the left side is the table of runs, its payload column travels with the ordering
+    nr = 30_000
+    tr = BASE + rng.integers(0, 40_000 * 4, nr) * 250_000
+    bid = rng.normal(0, 1, nr)
+    j = ops.asof_join_table(None, d(ts), None, d(tr), 1, [d(x)], [d(bid)], [None])
+    idx, _ = orc.asof_join(key, ts, np.zeros(nr, np.int32), tr, valid_r=[None])
+    idx = np.asarray(idx).reshape(-1, n)
+    order = np.lexsort((np.arange(n), ts))
+    assert np.array_equal(j["perm"].cpu().numpy().astype(np.int64), order)
+    assert np.array_equal(j["left"][0].cpu().numpy(), x[order])
+    hit = idx[0][order] >= 0
+    assert np.array_equal(j["right"][0][1].cpu().numpy() != 0, hit)
+    assert np.array_equal(j["right"][0][0].cpu().numpy()[hit], bid[idx[0][order][hit]])

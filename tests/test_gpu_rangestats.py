@@ -337,3 +337,33 @@ def test_profile_slots_from_several_host_threads(ops):
     for g in got:
         for name in ("perm", "count", "min", "max", "mean", "stddev"):
             assert torch.equal(g[name], want[name]), name
+
+
+def test_range_stats_long_frames_after_a_long_run_of_nulls(orc, ops):
+    """Frames of thousands of rows (the chunk-prefix path) over values far from 0 with a tiny
+    spread, where a run of NULLs longer than a chunk opens a 65 536-row superblock: the pivot of
+    the sums must still be a value of the data.  Standard deviation against an extended-precision
+    evaluation of a few frames, everything else against the oracle."""
+    rng = np.random.default_rng(31)
+    n = 200_000
+    ts = BASE + np.sort(rng.integers(0, 1_000_000_000, n))     # 1000 s, 200 rows per second
+    x = 1e6 + np.cumsum(rng.normal(0, 1e-3, n))
+    xv = np.ones(n, np.uint8)
+    xv[65_536 - 300:65_536 + 4000] = 0     # NULLs across the start of the second superblock
+    xv[131_072:131_072 + 1500] = 0         # ... and exactly from the start of the third
+    out = ops.range_stats(None, _dev(ts), _dev(x), _dev(xv), 1, 30)
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = orc.range_stats(np.zeros(n, np.int32), ts, x, xv, 30)
+    assert np.array_equal(g["perm"], ref["perm"]) and np.array_equal(g["count"], ref["count"])
+    assert np.array_equal(g["min"], ref["min"]) and np.array_equal(g["max"], ref["max"])
+    np.testing.assert_allclose(g["mean"], ref["mean"], rtol=1e-12)
+    sec = ts // 1_000_000
+    for i in (66_000, 70_000, 75_000, 131_500, 133_000, 140_000, n - 1):
+        m = (sec >= sec[i] - 30) & (sec <= sec[i]) & (xv != 0)
+        vals = x[m].astype(np.longdouble)
+        exact = float(np.sqrt(((vals - vals.mean()) ** 2).sum() / (len(vals) - 1)))
+        assert g["count"][i] == m.sum() > 1000
+        assert abs(g["stddev"][i] - exact) <= 1e-9 * exact, (i, g["stddev"][i], exact)
+    # the oracle's sequential recurrence (Spark's own) adds values of 1e6 to a running mean: with a
+    # spread of 1e-2 it keeps about seven digits of the standard deviation
+    np.testing.assert_allclose(g["stddev"], ref["stddev"], rtol=1e-6)
