@@ -272,7 +272,8 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_reduce_kernel(const uint32_
 // meets at most two big buckets -- the one holding its first row and the one holding its last.
 // ------------------------------------------------------------------------------------------
 struct BigAgg {
-  double sum, mean, m2;
+  double sum, mean, m2;  // mean: as an offset from `ref`
+  double ref;            // a value of the data the part's sums were taken around
   int64_t cnt;
   uint64_t isum, mn, mx;  // min / max as raw cell bits
   int32_t have;
@@ -290,7 +291,9 @@ __device__ __forceinline__ void agg_merge(BigAgg &a, const BigAgg &b, bool is_i)
     if (dlt(__longlong_as_double((long long)a.mx), __longlong_as_double((long long)b.mx))) a.mx = b.mx;
   }
   const double na = (double)a.cnt, nb = (double)b.cnt, nn = na + nb;
-  const double delta = b.mean - a.mean;
+  // the parts' means differ by little and sit far from 0 when the values do: form the difference
+  // from the offsets (the references subtract without rounding when they are close)
+  const double delta = (b.ref - a.ref) + (b.mean - a.mean);
   a.mean += delta * (nb / nn);
   a.m2 += b.m2 + delta * delta * (na * nb / nn);
   a.sum += b.sum;
@@ -303,6 +306,7 @@ __device__ __forceinline__ BigAgg agg_shfl_down(const BigAgg &a, int off) {
   r.sum = __shfl_down(a.sum, off, 64);
   r.mean = __shfl_down(a.mean, off, 64);
   r.m2 = __shfl_down(a.m2, off, 64);
+  r.ref = __shfl_down(a.ref, off, 64);
   r.cnt = __shfl_down(a.cnt, off, 64);
   r.isum = __shfl_down(a.isum, off, 64);
   r.mn = __shfl_down(a.mn, off, 64);
@@ -319,16 +323,29 @@ __device__ __forceinline__ BigAgg agg_rows(const uint32_t *perm, const ColPtrs &
   const bool is_i = cols.is_i64[k];
   const int64_t *ci = (const int64_t *)cols.col[k];
   const double *cd = (const double *)cols.col[k];
-  // pivot for the squared deviations: the first row's value when it is usable
+  // pivot for the squared deviations: the first usable value of the rows (searched 64 rows at a
+  // time -- a part that opens with NULLs must not fall back to 0, which would leave the squares of
+  // the values themselves to cancel)
   double pivot = 0.0;
-  {
-    uint32_t r0 = perm ? perm[lo] : (uint32_t)lo;
-    if (!valid || valid[r0]) {
-      double v = is_i ? (double)ci[r0] : cd[r0];
-      if (__builtin_isfinite(v)) pivot = v;
+  for (int64_t j0 = lo; j0 < hi; j0 += 64) {
+    const int64_t j = j0 + lane;
+    double v = 0.0;
+    bool ok = false;
+    if (j < hi) {
+      const uint32_t r = perm ? perm[j] : (uint32_t)j;
+      if (!valid || valid[r]) {
+        v = is_i ? (double)ci[r] : cd[r];
+        ok = __builtin_isfinite(v);
+      }
+    }
+    const uint64_t bal = __ballot(ok);
+    if (bal) {
+      pivot = __shfl(v, (int)__ffsll((long long)bal) - 1, 64);
+      break;
     }
   }
   BigAgg a;
+  a.ref = pivot;
   a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
   double sd = 0.0, sq = 0.0;
   for (int64_t j = lo + lane; j < hi; j += 64) {
@@ -358,7 +375,7 @@ __device__ __forceinline__ BigAgg agg_rows(const uint32_t *perm, const ColPtrs &
   }
   if (a.cnt > 0) {
     const double n = (double)a.cnt;
-    a.mean = pivot + sd / n;
+    a.mean = sd / n;
     a.m2 = sq - sd * sd / n;
     if (a.m2 < 0.0) a.m2 = 0.0;
   }
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(RB_THREADS) void bucket_big_tiles_kernel(const uint
       const int64_t s0 = blo > r0 ? blo : r0, s1 = bhi < r1 ? bhi : r1;
       for (int k = 0; k < n_cols; ++k) {
         BigAgg a;
+        a.ref = 0.0;
         a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
         if (big && !dup) a = agg_rows(perm, cols, k, s0, s1, lane);
         if (lane == 0) part[(size_t)(t * 2 + slot) * n_cols + k] = a;
@@ -414,6 +432,7 @@ __device__ __forceinline__ BigAgg agg_bucket(const BigAgg *part, int n_cols, int
                                              int64_t hi, int lane) {
   const int64_t t0 = lo / BB_TILE, t1 = (hi - 1) / BB_TILE;
   BigAgg a;
+  a.ref = 0.0;
   a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.cnt = 0; a.isum = 0; a.mn = 0; a.mx = 0; a.have = 0; a.pad = 0;
   for (int64_t t = t0 + lane; t <= t1; t += 64) {
     // in its first tile the bucket is slot 0 only if it holds that tile's first row

@@ -499,3 +499,28 @@ def test_resample_pick_without_ordering(orc, ops, func, feed, monkeypatch):
     assert r["n"] == e["n"]
     assert np.array_equal(r["key"].cpu().numpy(), e["key"]) and np.array_equal(r["start"].cpu().numpy(), e["start"])
     assert np.array_equal(r["row"].cpu().numpy().astype(np.int64), e["row"])
+
+
+def test_grouped_stats_big_buckets_whose_tiles_open_with_nulls(orc, ops, monkeypatch):
+    """Buckets of several hundred thousand rows are reduced tile by tile; the sums of a tile are
+    taken around a value of the tile even when its first rows are NULL.  A constant column has a
+    standard deviation of exactly 0 (as Spark's recurrence gives), and values far from 0 with a
+    small spread keep nine digits -- checked against an extended-precision evaluation."""
+    monkeypatch.setenv("TEMPO_NO_DENSE_STATS", "1")   # the ordered path's big-bucket kernels
+    rng = np.random.default_rng(8)
+    n = 400_000
+    ts = 1_596_240_000_000_000 + np.sort(rng.integers(0, 20 * 3600 * 1_000_000, n))   # one day, one key
+    const = np.full(n, 0.7306188)
+    level = 1e6 + np.cumsum(rng.normal(0, 1e-3, n))
+    v = (rng.random(n) >= 0.3).astype(np.uint8)
+    v[::512] = 0            # every tile of the ordered rows opens with a NULL, whatever its size
+    v[100_000:130_000] = 0  # and some with nothing but NULLs
+    r = ops.grouped_stats(None, _dev(ts), 1, 86_400_000_000, [_dev(const), _dev(level)], [_dev(v), _dev(v)])
+    e = orc.grouped_stats(np.zeros(n, np.int32), ts, 86_400_000_000, [const, level], [v, v])
+    assert r["n"] == e["n"] == 1 and int(r["count"][0][0]) == int(v.sum())
+    assert float(r["stddev"][0][0]) == 0.0 and float(e["stddev"][0][0]) == 0.0
+    vals = level[v != 0].astype(np.longdouble)
+    exact = float(np.sqrt(((vals - vals.mean()) ** 2).sum() / (len(vals) - 1)))
+    assert abs(float(r["stddev"][1][0]) - exact) <= 1e-9 * exact, (float(r["stddev"][1][0]), exact)
+    assert abs(float(r["mean"][1][0]) - float(vals.mean())) <= 1e-12 * 1e6
+    assert float(r["min"][1][0]) == float(vals.min()) and float(r["max"][1][0]) == float(vals.max())

@@ -421,8 +421,8 @@ def main():
                 desc = fn(rng)
                 status = "ok"
             except Exception as err:  # noqa: BLE001 (a harness: every failure is a finding)
-                desc = "%s: %s | %s" % (type(err).__name__, str(err).strip().splitlines()[0] if str(err).strip() else "",
-                                        LAST["desc"])
+                text = [t.strip() for t in str(err).strip().splitlines() if t.strip()]
+                desc = "%s: %s | %s" % (type(err).__name__, " / ".join(text[:7]), LAST["desc"])
                 status = "MISMATCH" if isinstance(err, AssertionError) else "ERROR"
                 bad.append(dict(op=name, case_seed=case_seed, status=status, what=desc,
                                 trace=traceback.format_exc().splitlines()[-6:]))
