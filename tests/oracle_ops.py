@@ -62,7 +62,7 @@ def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, rig
         slot = mask_of[c]
         src = idx[1 + slot] if (skip_nulls and slot >= 0) else idx[0]
         ok = src >= 0
-        if not skip_nulls and slot >= 0:
+        if not skip_nulls and slot >= 0 and nR:
             ok = ok & (_np(masks[slot])[np.maximum(src, 0)] != 0)
         vals = np.where(ok, v[np.maximum(src, 0)], 0) if nR else np.zeros(nL, v.dtype)
         right.append((_t(vals[perm].astype(v.dtype)), _t(ok[perm].astype(np.uint8))))
