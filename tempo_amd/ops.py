@@ -154,6 +154,12 @@ def _asof_join_once(key_l, ts_l, key_r, ts_r, n_keys, seq_r=None, seq_r_valid=No
     return idx[:, 0], idx[:, 1:].t(), missing
 
 
+def _same_mask_key(m):
+    """Two right columns share a validity mask when they were given the same memory.  Empty
+    tensors all report the same (null) address, so those are told apart by object identity."""
+    return ("ptr", m.data_ptr()) if m.numel() else ("obj", id(m))
+
+
 def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
                     skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
                     ts_partition_val=None, fraction=0.5):
@@ -170,9 +176,9 @@ def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, rig
         taken = {}  # one selection per distinct mask, so that shared masks stay shared
         sub_masks = []
         for m in right_col_masks:
-            if m is not None and m.data_ptr() not in taken:
-                taken[m.data_ptr()] = _take(m, sel_r)
-            sub_masks.append(None if m is None else taken[m.data_ptr()])
+            if m is not None and _same_mask_key(m) not in taken:
+                taken[_same_mask_key(m)] = _take(m, sel_r)
+            sub_masks.append(None if m is None else taken[_same_mask_key(m)])
         j = asof_join_table(_take(key_l, sel_l) - lo, _take(ts_l, sel_l), _take(key_r, sel_r) - lo, _take(ts_r, sel_r),
                             hi - lo, [_take(c, sel_l) for c in left_cols], [_take(c, sel_r) for c in right_cols],
                             sub_masks, skip_nulls, _take(seq_r, sel_r), _take(seq_r_valid, sel_r), ts_is_seconds,
@@ -221,7 +227,7 @@ def _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_col
             mask_of.append(-1); rule.append(-1); vmask.append(-1)
             continue
         _dev(m, torch.uint8, f"right_col_masks[{i}]", nR)
-        slot = next((k for k, mm in enumerate(masks) if mm.data_ptr() == m.data_ptr()), None)
+        slot = next((k for k, mm in enumerate(masks) if _same_mask_key(mm) == _same_mask_key(m)), None)
         if slot is None:
             slot = len(masks)
             masks.append(m)

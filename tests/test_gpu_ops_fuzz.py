@@ -18,6 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # NULLs (seed 1000194, 24 s of oracle time) has a test of its own in test_gpu_rangestats.py.
 FOUND = [1000108, 2000179, 2000592, 2000850, 2001937]
 SEEDS = FOUND + [7 * 1_000_003 + i for i in range(60)]
+# second pool (wide-word joins, shuffle routing, write layout); the first two: a right table of one
+# to three rows left one half of the key dictionary without right rows, whose empty validity masks
+# were then taken for one and the same
+EXTRA_SEEDS = [4000104, 4000211] + [9 * 1_000_003 + i for i in range(30)]
 
 
 @pytest.fixture(scope="module")
@@ -27,6 +31,15 @@ def fz(orc):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_ops
     return fuzz_ops
+
+
+@pytest.mark.parametrize("case_seed", EXTRA_SEEDS)
+def test_operator_fuzz_case_second_pool(fz, case_seed, monkeypatch):
+    monkeypatch.delenv("TEMPO_PLAIN_SORT", raising=False)
+    rng = np.random.default_rng(case_seed)
+    name, fn, _ = fz.EXTRA_CASES[int(rng.choice(len(fz.EXTRA_CASES), p=np.full(len(fz.EXTRA_CASES), 1.0 / len(fz.EXTRA_CASES))))]
+    fn(rng)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("case_seed", SEEDS)

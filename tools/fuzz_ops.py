@@ -387,8 +387,77 @@ def case_interpolate(rng):
     return desc
 
 
+def case_asof_wide(rng):
+    """Tables whose key, time and sequence fields or validity bits do not fit one 64-bit sort word:
+    many keys, a year of microseconds, a sequence column, up to 8 nullable right columns."""
+    n_keys = int(rng.choice([300_000, 1_000_000]))
+    nl, nr = min(draw_size(rng), 300_000), min(draw_size(rng), 300_000)
+    year = 365 * 86_400 * 1_000_000
+    kl, kr = rng.integers(0, n_keys, nl).astype(np.int32), rng.integers(0, n_keys, nr).astype(np.int32)
+    if rng.random() < 0.5:  # few distinct keys out of a large dictionary: ties and real matches
+        kl, kr = (kl % 50) * (n_keys // 50), (kr % 50) * (n_keys // 50)
+    tl, tr = BASE + rng.integers(0, year, nl), BASE + rng.integers(0, year, nr)
+    seq, seqv = (rng.integers(0, 1 << 20, nr), (rng.random(nr) > 0.2).astype(np.uint8)) if rng.random() < 0.6 else (None, None)
+    masks = [(rng.random(nr) >= 0.3).astype(np.uint8) for _ in range(int(rng.integers(0, 9)))]
+    desc = LAST["desc"] = "asof_wide nl=%d nr=%d keys=%d masks=%d seq=%s" % (nl, nr, n_keys, len(masks), seq is not None)
+    rcols = [rng.normal(0, 1, nr) for _ in range(max(1, len(masks)))]
+    col_mask = [c if c < len(masks) else None for c in range(len(rcols))]
+    dmasks, hmasks = [dev(m) for m in masks], [host(m) for m in masks]
+    j = ops.asof_join_table(dev(kl), dev(tl), dev(kr), dev(tr), n_keys, [], [dev(c) for c in rcols],
+                            [None if c is None else dmasks[c] for c in col_mask], seq_r=dev(seq), seq_r_valid=dev(seqv))
+    e = orc.asof_join_table(host(kl), host(tl), host(kr), host(tr), n_keys, [], [host(c) for c in rcols],
+                            [None if c is None else hmasks[c] for c in col_mask], seq_r=host(seq), seq_r_valid=host(seqv))
+    eq(j["perm"], e["perm"], "perm")
+    eq(j["key"], e["key"], "key")
+    eq(j["ts"], e["ts"], "ts")
+    for c in range(len(rcols)):
+        ok = torch.from_numpy(e["right"][c][1].numpy() != 0)
+        eq(j["right"][c][1], e["right"][c][1], "right validity %d" % c)
+        eq(j["right"][c][0].cpu()[ok], e["right"][c][0][ok], "right column %d" % c)
+    return desc
+
+
+def case_partition(rng):
+    """The shuffle's routing: rows bucketed by owner (hash or owner table), every column moved."""
+    import host_partition as hp
+    n = max(1, draw_size(rng))
+    n_keys = int(rng.choice([1, 3, 40, 5000]))
+    n_parts = int(rng.choice([1, 2, 3, 8, 64]))
+    key = rng.integers(0, n_keys, n).astype(np.int32)
+    table = rng.integers(0, n_parts, n_keys).astype(np.int32) if rng.random() < 0.5 else None
+    cols = [rng.integers(0, 1 << 60, n), rng.normal(0, 1, n), (rng.random(n) > 0.5).astype(np.uint8),
+            rng.integers(0, 1 << 30, n).astype(np.int32)][:int(rng.integers(1, 5))]
+    desc = LAST["desc"] = "partition n=%d keys=%d parts=%d table=%s cols=%d" % (n, n_keys, n_parts, table is not None, len(cols))
+    owner = hp.owners_of(key, n_parts, table)
+    perm = np.argsort(owner, kind="stable")
+    counts = np.bincount(owner, minlength=n_parts)
+    outs, got_counts = ops.partition_move(dev(key), [dev(c) for c in cols], n_parts, owner_table=dev(table))
+    eq(got_counts, counts, "counts")
+    for c in range(len(cols)):
+        eq(outs[c], cols[c][perm], "column %d" % c)
+    p2, c2 = ops.hash_partition(dev(key), n_parts, owner_table=dev(table))
+    eq(c2, counts, "counts (perm form)")
+    eq(p2, perm, "perm")
+    return desc
+
+
+def case_write_layout(rng):
+    n_keys = int(rng.choice([1, 9, 300]))
+    n = max(1, min(draw_size(rng), 400_000))
+    key, ts, shape = draw_table(rng, n, n_keys, pre_epoch=bool(rng.random() < 0.2))
+    ts = ts + rng.integers(0, 40, n) * 86_400_000_000   # several days
+    desc = LAST["desc"] = "write_layout n=%d(%s) keys=%d" % (n, shape, n_keys)
+    got = ops.write_layout(dev(key), dev(ts), n_keys)
+    want = orc.write_layout(host(key), host(ts), n_keys)
+    for name, g, w in zip(("event_dt", "event_time", "perm", "dt_range"), got, want):
+        eq(g, w, name)
+    return desc
+
+
 CASES = [("asof", case_asof, 4), ("range_stats", case_range_stats, 3), ("ema", case_ema, 1), ("lookback", case_lookback, 1),
          ("resample", case_resample, 2), ("grouped_stats", case_grouped, 2), ("interpolate", case_interpolate, 1)]
+# a pool of its own (--extra), so that the case a seed of the first pool names stays the same
+EXTRA_CASES = [("asof_wide", case_asof_wide, 1), ("partition", case_partition, 1), ("write_layout", case_write_layout, 1)]
 
 
 def main():
@@ -397,11 +466,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0 = by time only)")
     ap.add_argument("--case-seed", type=int, default=0, help="run this one case again (the seed a log line names)")
+    ap.add_argument("--extra", action="store_true",
+                    help="the second pool: joins of tables wider than one sort word, shuffle routing, write layout")
     ap.add_argument("--only", default="", help="comma-separated operator names")
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "fuzz_ops.log"))
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.log), exist_ok=True)
-    pool = [c for c in CASES if not args.only or c[0] in args.only.split(",")]
+    pool = [c for c in (EXTRA_CASES if args.extra else CASES) if not args.only or c[0] in args.only.split(",")]
     weights = np.array([c[2] for c in pool], dtype=np.float64)
     weights /= weights.sum()
     t_end = time.time() + args.seconds
