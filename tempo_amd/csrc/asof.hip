@@ -36,7 +36,7 @@ static inline int rec_stride(int n_cols) {
   return (n_cols + 3) & ~3;
 }
 
-constexpr int kUnits = 4096;     // waves that each scan one contiguous slice of the right side
+constexpr int kUnits = kLastValidUnits;  // waves that each scan one contiguous slice of the right side
 constexpr int kUnitBlock = 256;  // 4 waves per block
 constexpr int kRowsPerIter = 64 * 4;
 
@@ -171,6 +171,13 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
 }
 
 size_t last_valid_scratch_ints() { return (size_t)TMP_MAX_MASKS * kUnits; }
+
+int last_valid_unit_carry(int32_t *unit_agg, int units, int n_masks, hipStream_t st) {
+  if (n_masks <= 0 || units <= 0) return TMP_OK;
+  TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, units);
+  TMP_CHECK_HIP(hipGetLastError());
+  return TMP_OK;
+}
 
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
                     bool reverse, hipStream_t st, const uint16_t *ext) {
@@ -536,7 +543,9 @@ static void asof_plan(const tmp_asof_args *a, Workspace &ws, AsofPlan *p) {
   p->lastnn = ws.take<int32_t>(nm * (size_t)(a->n_right > 0 ? a->n_right : 1));
   p->unit_agg = ws.take<int32_t>(last_valid_scratch_ints());
   p->cmask = ws.take<uint16_t>(a->n_masks > 0 ? (size_t)(a->n_right > 0 ? a->n_right : 1) : 1);
-  p->block_bounds = ws.take<int64_t>((size_t)(a->n_left / (kBlock * kMergeRows) + 3));
+  size_t n_bounds = (size_t)(a->n_left / (kBlock * kMergeRows) + 3);
+  if (asof_sorted_bounds_count(a->n_left) > n_bounds) n_bounds = asof_sorted_bounds_count(a->n_left);
+  p->block_bounds = ws.take<int64_t>(n_bounds);
   const int nlc = a->sorted_output ? a->n_left_cols : 0;
   p->lrec = ws.take<uint64_t>(nlc >= 2 ? (size_t)rec_stride(nlc) * (size_t)a->n_left : 2);
   p->rrec = ws.take<uint64_t>(nrec >= 2 ? (size_t)rec_stride(nrec) * (size_t)a->n_right : 2);
@@ -629,6 +638,16 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   RangeInfo rl, rr;
   TMP_TRY(order_read_ranges(p.lb, &rl, st));
   TMP_TRY(order_read_ranges(p.rb, &rr, st));
+  SkewParams sp;
+  sp.enabled = a->skew != 0;
+  sp.v_is_int = a->v_is_int;
+  sp.ts_is_seconds = a->ts_is_seconds;
+  sp.v = a->ts_partition_val;
+  sp.one_minus_fraction = a->one_minus_fraction;
+  // both sides arrive in order: one sweep over the columns, nothing laid out (TEMPO_NO_SORTED_JOIN=1
+  // sends such tables down the general path, for comparison)
+  if (!rl.unsorted && !rr.unsorted && a->n_right > 0 && !getenv("TEMPO_NO_SORTED_JOIN"))
+    return asof_sorted_join(a, sp, p.block_bounds, p.lastnn, p.unit_agg, st);
   RangeInfo both = rr;
   both.prim_min = rl.prim_min < rr.prim_min ? rl.prim_min : rr.prim_min;
   both.prim_max = rl.prim_max > rr.prim_max ? rl.prim_max : rr.prim_max;
@@ -733,12 +752,6 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   }
   TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, rst, cmask));
   TMP_CHECK_HIP(side_join.join());
-  SkewParams sp;
-  sp.enabled = a->skew != 0;
-  sp.v_is_int = a->v_is_int;
-  sp.ts_is_seconds = a->ts_is_seconds;
-  sp.v = a->ts_partition_val;
-  sp.one_minus_fraction = a->one_minus_fraction;
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(merge_bounds_kernel, dim3((grid + 1 + kBlock - 1) / kBlock), dim3(kBlock), st, lo.comp, a->n_left, ro.comp,
              a->n_right, lay.low_bits, kBlock * kMergeRows, (int64_t)grid, p.block_bounds);

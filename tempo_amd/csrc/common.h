@@ -230,8 +230,23 @@ size_t last_valid_scratch_ints();
 // ext: the mask bits as a separate array (Layout::ext_masks) instead of the words' low bits.
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
                     bool reverse, hipStream_t st, const uint16_t *ext = nullptr);
+// The scan works in kLastValidUnits slices ("units"); unit_agg is laid out [mask][kLastValidUnits].
+constexpr int kLastValidUnits = 4096;
+// In place, per mask m < n_masks: unit_agg[m][u] (last set position inside unit u, or -1) becomes the
+// last set position before unit u, or -1 (u < units <= kLastValidUnits).
+int last_valid_unit_carry(int32_t *unit_agg, int units, int n_masks, hipStream_t st);
 // Exclusive scan of `total` uint32 counters in place.
 int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st);
+
+// AS-OF join of two tables that are both in (key, ts[, seq]) order already (asof_sorted.hip): no
+// sort words, no row ids; reads the argument block's columns directly.  bounds:
+// asof_sorted_bounds_count(n_left) int64; tile_table: asof_sorted_table_ints(n_right, n_masks) int32;
+// unit_agg: last_valid_scratch_ints() int32.
+struct SkewParams;
+size_t asof_sorted_bounds_count(int64_t n_left);
+size_t asof_sorted_table_ints(int64_t n_right, int n_masks);
+int asof_sorted_join(const tmp_asof_args *a, const SkewParams &sp, int64_t *bounds, int32_t *tile_table,
+                     int32_t *unit_agg, hipStream_t st);
 
 // floor(a / b), b > 0 expected (negative b falls through to the exact path).  For divisors up
 // to 2^40 the quotient comes from a double-precision estimate that exact integer remainder steps
