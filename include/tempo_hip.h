@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TMP_ABI_VERSION 1
+#define TMP_ABI_VERSION 2
 
 #define TMP_OK 0
 #define TMP_EINVAL (-1)       /* bad argument */
@@ -147,6 +147,12 @@ typedef struct {
   void *const *out_right_cols;
   uint8_t *const *out_right_valid; /* entries may be NULL */
   int32_t *out_missing;  /* [1 + n_masks] */
+  /* HOST pointer, optional (sorted_output only).  Non-NULL: the caller can use the left table by
+   * reference.  When the call finds the left table already in (key, ts) order -- row p of the
+   * result is then left row p -- it stores 1 here and leaves out_perm, out_key, out_ts and
+   * out_left_cols unwritten (they would be copies of the caller's own columns); otherwise it
+   * stores 0 and writes them as described above. */
+  int32_t *left_in_place;
 } tmp_asof_args;
 
 /* Streams: every kernel runs on `stream`.  With TEMPO_JOIN_STREAMS=1 in the environment and both

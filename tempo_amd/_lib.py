@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtempo_hip.so")
+# TEMPO_HIP_LIB: another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("TEMPO_HIP_LIB") or os.path.join(_HERE, "libtempo_hip.so")
 
 TMP_MAX_MASKS = 16
 TMP_MAX_JOIN_COLS = 16
@@ -39,7 +40,7 @@ class AsofArgs(C.Structure):
                 ("n_right_cols", C.c_int32), ("right_cols", C.POINTER(_vp)),
                 ("right_col_rule", C.POINTER(C.c_int32)), ("right_col_valid", C.POINTER(C.c_int32)),
                 ("out_right_cols", C.POINTER(_vp)), ("out_right_valid", C.POINTER(_vp)),
-                ("out_missing", _vp)]
+                ("out_missing", _vp), ("left_in_place", C.POINTER(C.c_int32))]
 
 
 class RangeStatsArgs(C.Structure):
@@ -207,7 +208,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the build lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if handle.tmp_abi_version() != 1:
+        if handle.tmp_abi_version() != 2:
             raise TempoHipError("libtempo_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

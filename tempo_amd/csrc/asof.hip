@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     uint32_t key_l = lay.key_of(wl);
     bool same = jr >= blo && lay.key_of(wr_row) == key_l;
     double part_l = 0.0;
-    if (sp.enabled) part_l = bracket_part(bracket_seconds(lay.prim_of(wl), sp), sp);
+    if (sp.enabled) part_l = bracket_part_ts(lay.prim_of(wl), sp);
     uint32_t src_row = src_pre[r];
     uint32_t dst = sorted_output ? (uint32_t)i : src_row;
     int32_t jpre[4];
@@ -606,6 +606,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   clear_error();
   TMP_TRY(asof_validate(a));
   hipStream_t st = (hipStream_t)stream;
+  if (a->left_in_place) *a->left_in_place = 0;
   TMP_CHECK_HIP(hipMemsetAsync(a->out_missing, 0, sizeof(int32_t) * (1 + a->n_masks), st));
   if (a->n_left == 0) return TMP_OK;
   Workspace ws(workspace, workspace_bytes);
@@ -639,11 +640,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   TMP_TRY(order_read_ranges(p.lb, &rl, st));
   TMP_TRY(order_read_ranges(p.rb, &rr, st));
   SkewParams sp;
-  sp.enabled = a->skew != 0;
-  sp.v_is_int = a->v_is_int;
-  sp.ts_is_seconds = a->ts_is_seconds;
-  sp.v = a->ts_partition_val;
-  sp.one_minus_fraction = a->one_minus_fraction;
+  skew_params_set(&sp, a->skew != 0, a->v_is_int, a->ts_is_seconds, a->ts_partition_val, a->one_minus_fraction);
   // both sides arrive in order: one sweep over the columns, nothing laid out (TEMPO_NO_SORTED_JOIN=1
   // sends such tables down the general path, for comparison)
   if (!rl.unsorted && !rr.unsorted && a->n_right > 0 && !getenv("TEMPO_NO_SORTED_JOIN"))

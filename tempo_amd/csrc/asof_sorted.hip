@@ -5,7 +5,7 @@
 // it back in the merge.  Here nothing is built:
 //   1. per 512 right rows and NULL mask, the last row whose mask byte is set (reads the mask bytes
 //      only), turned into "last valid row before this stretch" by a two-level running maximum;
-//   2. per block of 1024 left rows, the number of right rows ordered at or before its first row
+//   2. per block of 512 left rows, the number of right rows ordered at or before its first row
 //      (one binary search over the right key / time columns);
 //   3. one kernel: a block stages the slice of right (key, time) its rows can match in LDS, with
 //      one bitmap per NULL mask built from wave ballots; every left row searches the slice, applies
@@ -22,10 +22,23 @@
 
 namespace tmp {
 
-constexpr int SJ_THREADS = 256;
-constexpr int SJ_ROWS = 4;                     // left rows per thread
+#ifndef TEMPO_SJ_THREADS
+#define TEMPO_SJ_THREADS 256
+#endif
+constexpr int SJ_THREADS = TEMPO_SJ_THREADS;
+#ifndef TEMPO_SJ_ROWS
+#define TEMPO_SJ_ROWS 2
+#endif
+constexpr int SJ_ROWS = TEMPO_SJ_ROWS;         // consecutive left rows per thread: 2 or 4
+static_assert(SJ_ROWS == 2 || SJ_ROWS == 4, "the wide accesses are written for two or four rows");
 constexpr int SJ_TILE = SJ_THREADS * SJ_ROWS;  // left rows per block
-constexpr int SJ_CAP = 2560;                   // right rows staged at a time
+#ifndef TEMPO_SJ_CAP
+#define TEMPO_SJ_CAP 768
+#endif
+#ifndef TEMPO_SJ_WAVES
+#define TEMPO_SJ_WAVES 8
+#endif
+constexpr int SJ_CAP = TEMPO_SJ_CAP;           // right rows staged at a time
 constexpr int SJ_WORDS = SJ_CAP / 64;
 constexpr int SJ_RTILE = 512;                  // right rows per entry of the last-valid table
 constexpr int SJ_SEQ = TMP_MAX_MASKS;          // bitmap slot of "the row's sequence value is not NULL"
@@ -56,6 +69,9 @@ struct SjCols {
   uint8_t *out_valid[TMP_MAX_JOIN_COLS];
   int8_t rule[TMP_MAX_JOIN_COLS];   // -1: last visible row; m: last visible row with mask m valid
   int8_t vmask[TMP_MAX_JOIN_COLS];  // -1: never NULL once matched; m: NULL where mask m is 0
+  // joined column that is the right table's own time column under the row rule, or -1: its values
+  // are taken from the staged slice instead of being read a second time
+  int ts_col;
 };
 
 // Is the right row (kr, tr, sequence present?) ordered at or before the left row (kl, tl)?  Left
@@ -113,7 +129,29 @@ __global__ __launch_bounds__(256) void sj_tile_last_kernel(SjMasks mk, int64_t n
   for (int m = 0; m < mk.n; ++m) {
     const uint8_t *p = mk.p[m];
     int32_t ulast = -1;
-    for (int64_t t = t0; t < t1; ++t) {
+    int64_t t = t0;
+    if (((uintptr_t)p & 7) == 0) {
+      // whole tiles, four at a time: a lane reads eight mask bytes of each, the tile's last set byte
+      // is the highest set byte of the highest lane that saw one
+      for (; t + 4 <= t1 && (t + 4) * SJ_RTILE <= n; t += 4) {
+        uint64_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = reinterpret_cast<const uint64_t *>(p + (t + u) * SJ_RTILE)[lane];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t bal = __ballot(w[u] != 0);
+          int32_t last = -1;
+          if (bal) {
+            const int top = 63 - __clzll((long long)bal);
+            const int byte = (63 - __clzll((long long)(w[u] | 1ull))) >> 3;
+            last = (int32_t)((t + u) * SJ_RTILE + top * 8 + __shfl(byte, top, 64));
+          }
+          if (lane == 0) tile_last[(size_t)m * g.n_tiles + t + u] = last;
+          ulast = last >= 0 ? last : ulast;
+        }
+      }
+    }
+    for (; t < t1; ++t) {
       const int64_t base = t * SJ_RTILE;
       uint8_t v[SJ_RTILE / 64];
 #pragma unroll
@@ -152,20 +190,53 @@ __global__ __launch_bounds__(kBlock) void sj_tile_carry_kernel(int n_masks, SjGe
   }
 }
 
-// A thread owns four consecutive left rows (their columns come and go as 16-byte accesses when
+// SJ_ROWS consecutive elements as the widest accesses that cover them (the caller has checked alignment).
+__device__ __forceinline__ void sj_load64(const uint64_t *p, uint64_t v[SJ_ROWS]) {
+#pragma unroll
+  for (int r = 0; r < SJ_ROWS; r += 2) {
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p + r);
+    v[r] = a.x; v[r + 1] = a.y;
+  }
+}
+__device__ __forceinline__ void sj_store64(uint64_t *p, const uint64_t v[SJ_ROWS]) {
+#pragma unroll
+  for (int r = 0; r < SJ_ROWS; r += 2) *reinterpret_cast<ulonglong2 *>(p + r) = make_ulonglong2(v[r], v[r + 1]);
+}
+__device__ __forceinline__ void sj_load32(const int32_t *p, int32_t v[SJ_ROWS]) {
+  if constexpr (SJ_ROWS == 4) {
+    const int4 a = *reinterpret_cast<const int4 *>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+    const int2 a = *reinterpret_cast<const int2 *>(p);
+    v[0] = a.x; v[1] = a.y;
+  }
+}
+__device__ __forceinline__ void sj_store32(int32_t *p, const int32_t v[SJ_ROWS]) {
+  if constexpr (SJ_ROWS == 4) *reinterpret_cast<int4 *>(p) = make_int4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<int2 *>(p) = make_int2(v[0], v[1]);
+}
+__device__ __forceinline__ void sj_store8(uint8_t *p, const uint8_t v[SJ_ROWS]) {
+  if constexpr (SJ_ROWS == 4) *reinterpret_cast<uchar4 *>(p) = make_uchar4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<uchar2 *>(p) = make_uchar2(v[0], v[1]);
+}
+
+// A thread owns SJ_ROWS consecutive left rows (their columns come and go as 8- or 16-byte accesses when
 // `vec` says every pointer involved is aligned for it); consecutive rows have neighbouring places
-// in the right table, so only the first of the four is found by a full binary search over the staged
-// slice, the others by galloping on from their predecessor's place.
+// in the right table, so only the first of them is found by a full binary search over the staged
+// slice, the others by galloping on from their predecessor's place.  What bounds the kernel is the
+// number of waves a CU holds (every phase is a round trip to memory or a chain of LDS probes):
+// two rows per thread and a 768-row staging buffer keep it at 64 registers and 12 KB of LDS, eight
+// waves per SIMD -- 5 x 10^8 + 5 x 10^8 rows: 8.9 ms, against 11.8 ms with four rows and 2048.
 //
 // NC, NM > 0: at most NC joined columns and NM masks; the loops over them are unrolled, which turns
 // the per-column fields of the argument block into one-time scalar loads and keeps the rows' chosen
 // positions in registers.  NC = NM = 0: any number.
 template <int NC, int NM>
-__global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks mk, SkewParams sp, SjCols jc,
+__global__ __launch_bounds__(SJ_THREADS, TEMPO_SJ_WAVES) void sj_merge_kernel(SjSides s, SjMasks mk, SkewParams sp, SjCols jc,
                                                               const int64_t *bounds, const int32_t *tile_carry,
                                                               int64_t n_rtiles, int32_t *out_idx, int32_t *out_missing,
                                                               int sorted_output, int32_t *out_perm, int32_t *out_key,
-                                                              int64_t *out_ts, int vec) {
+                                                              int64_t *out_ts, int vec, int by_ref) {
   __shared__ int64_t s_ts[SJ_CAP];
   __shared__ int32_t s_key[SJ_CAP];
   __shared__ uint64_t s_bm[TMP_MAX_MASKS + 1][SJ_WORDS];  // one bit per staged row and mask; slot SJ_SEQ: sequence present
@@ -173,7 +244,7 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
   __shared__ int32_t s_carry[TMP_MAX_MASKS];               // last valid row before the staged chunk
   constexpr int kColLoop = NC > 0 ? NC : TMP_MAX_JOIN_COLS;
   constexpr int kMaskLoop = NM > 0 ? NM : TMP_MAX_MASKS;
-  constexpr int kStage = NM > 0 ? 5 : 2;  // staging steps whose loads are requested together
+  constexpr int kStage = NM > 0 ? (SJ_CAP / SJ_THREADS < 4 ? SJ_CAP / SJ_THREADS : 4) : 2;  // staging steps whose loads are requested together
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_masks = mk.n;
   const int64_t tile = (int64_t)blockIdx.x * SJ_TILE;
@@ -186,15 +257,20 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
   const int64_t b0 = bounds[blockIdx.x];
   const int64_t blo = b0 > 0 ? b0 - 1 : 0, bhi = bounds[blockIdx.x + 1];
 
+#ifdef SJ_TIMING
+  long long tk[12]; int ntk = 0;
+#define SJTICK() do { __syncthreads(); tk[ntk < 11 ? ntk++ : 11] = clock64(); } while (0)
+#else
+#define SJTICK() do {} while (0)
+#endif
+  SJTICK();
   int32_t kl[SJ_ROWS];
   int64_t tl[SJ_ROWS];
   if (wide) {
-    const longlong2 ta = *reinterpret_cast<const longlong2 *>(s.ts_l + i0);
-    const longlong2 tb = *reinterpret_cast<const longlong2 *>(s.ts_l + i0 + 2);
-    int4 k4 = make_int4(0, 0, 0, 0);
-    if (s.key_l) k4 = *reinterpret_cast<const int4 *>(s.key_l + i0);
-    tl[0] = ta.x; tl[1] = ta.y; tl[2] = tb.x; tl[3] = tb.y;
-    kl[0] = k4.x; kl[1] = k4.y; kl[2] = k4.z; kl[3] = k4.w;
+    sj_load64(reinterpret_cast<const uint64_t *>(s.ts_l + i0), reinterpret_cast<uint64_t *>(tl));
+#pragma unroll
+    for (int r = 0; r < SJ_ROWS; ++r) kl[r] = 0;
+    if (s.key_l) sj_load32(s.key_l + i0, kl);
   } else {
 #pragma unroll
     for (int r = 0; r < SJ_ROWS; ++r) {
@@ -203,13 +279,13 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
       tl[r] = s.ts_l[i];
     }
   }
-  // left payload: the table is in order already, its columns pass through
-  for (int c = 0; c < jc.n_left; ++c) {
+  // left payload: the table is in order already, its columns pass through (by_ref: the caller uses
+  // its own columns, nothing is copied)
+  for (int c = 0; c < (by_ref ? 0 : jc.n_left); ++c) {
     if (wide) {
-      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(jc.lsrc[c] + i0);
-      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(jc.lsrc[c] + i0 + 2);
-      *reinterpret_cast<ulonglong2 *>(jc.lout[c] + i0) = a;
-      *reinterpret_cast<ulonglong2 *>(jc.lout[c] + i0 + 2) = b;
+      uint64_t v[SJ_ROWS];
+      sj_load64(jc.lsrc[c] + i0, v);
+      sj_store64(jc.lout[c] + i0, v);
     } else {
       for (int r = 0; r < nrow; ++r) jc.lout[c][i0 + r] = jc.lsrc[c][i0 + r];
     }
@@ -236,14 +312,17 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
     }
   }
 
+  SJTICK();  // 1: left rows, pass-through, carry-in
   bool done[SJ_ROWS];
   int32_t jrow[SJ_ROWS];
   int32_t jm[SJ_ROWS][kMaskLoop];
   uint32_t okbits[SJ_ROWS];
+  int64_t tjoin[SJ_ROWS];  // time of the row chosen by the row rule
 #pragma unroll
   for (int r = 0; r < SJ_ROWS; ++r) {
     done[r] = r >= nrow;
     jrow[r] = -1;
+    tjoin[r] = 0;
     okbits[r] = 0;
 #pragma unroll
     for (int m = 0; m < kMaskLoop; ++m) jm[r][m] = -1;
@@ -289,6 +368,7 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
       }
     }
     __syncthreads();
+    SJTICK();  // 2: staged
     const int nwords = (len + 63) >> 6;
     for (int m = wave; m < n_masks; m += SJ_THREADS / 64) {
       int32_t v = -1;
@@ -308,6 +388,7 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
     }
     __syncthreads();
 
+    SJTICK();  // 3: prefix
     // ---- places of this thread's rows in the staged chunk (LDS only; a candidate that lies
     // before the chunk is looked up in the table itself)
     int from = -1;  // place of the previous row looked at in this chunk, or -1: none yet
@@ -339,8 +420,11 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
       const int q = lo - 1;  // staged index of the last right row at or before this one
       const bool same = q >= 0 && s_key[q] == kl[r];
       double part_l = 0.0;
-      if (sp.enabled) part_l = bracket_part(bracket_seconds(tl[r], sp), sp);
-      if (same && (!sp.enabled || bracket_visible(s_ts[q], part_l, sp))) jrow[r] = (int32_t)(cs + q);
+      if (sp.enabled) part_l = bracket_part_ts(tl[r], sp);
+      if (same && (!sp.enabled || bracket_visible(s_ts[q], part_l, sp))) {
+        jrow[r] = (int32_t)(cs + q);
+        tjoin[r] = s_ts[q];
+      }
       miss_row |= jrow[r] < 0;
 #pragma unroll
       for (int m = 0; m < kMaskLoop; ++m) {
@@ -390,6 +474,7 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
         okbits[r] |= (uint32_t)ok << c;
       }
     }
+    SJTICK();  // 4: search + rules
     if (last_chunk) break;
     __syncthreads();  // every row has read the staged chunk
     for (int m = wave; m < n_masks; m += SJ_THREADS / 64)
@@ -397,15 +482,15 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
     cs = ce - 1;  // chunks overlap by one row: the row before a place is always staged with it
   }
 
-  // ---- the rows of the joined table: values by position in the right table, four rows at a time
-  if (sorted_output && nrow > 0) {
+  // ---- the rows of the joined table: values by position in the right table
+  if (sorted_output && nrow > 0 && !by_ref) {
     if (wide) {
-      *reinterpret_cast<int4 *>(out_perm + i0) = make_int4((int)i0, (int)i0 + 1, (int)i0 + 2, (int)i0 + 3);
-      if (out_key) *reinterpret_cast<int4 *>(out_key + i0) = make_int4(kl[0], kl[1], kl[2], kl[3]);
-      if (out_ts) {
-        *reinterpret_cast<longlong2 *>(out_ts + i0) = make_longlong2(tl[0], tl[1]);
-        *reinterpret_cast<longlong2 *>(out_ts + i0 + 2) = make_longlong2(tl[2], tl[3]);
-      }
+      int32_t ids[SJ_ROWS];
+#pragma unroll
+      for (int r = 0; r < SJ_ROWS; ++r) ids[r] = (int32_t)i0 + r;
+      sj_store32(out_perm + i0, ids);
+      if (out_key) sj_store32(out_key + i0, kl);
+      if (out_ts) sj_store64(reinterpret_cast<uint64_t *>(out_ts + i0), reinterpret_cast<const uint64_t *>(tl));
     } else {
       for (int r = 0; r < nrow; ++r) {
         out_perm[i0 + r] = (int32_t)(i0 + r);
@@ -425,41 +510,56 @@ __global__ __launch_bounds__(SJ_THREADS) void sj_merge_kernel(SjSides s, SjMasks
         if (m < n_masks) rec[1 + m] = jm[r][m];
     }
   }
-  uint64_t val[kColLoop][SJ_ROWS];
+  // four columns at a time: their values requested together, then their stores
 #pragma unroll
-  for (int c = 0; c < kColLoop; ++c) {
+  for (int c0 = 0; c0 < kColLoop; c0 += 4) {
+    uint64_t val[4][SJ_ROWS];
 #pragma unroll
-    for (int r = 0; r < SJ_ROWS; ++r) {
-      val[c][r] = 0;
-      if (c >= jc.n || !((okbits[r] >> c) & 1u)) continue;
-      int32_t j = jrow[r];
-      const int rl = jc.rule[c];
-      if (rl >= 0) {
-#pragma unroll
-        for (int m = 0; m < kMaskLoop; ++m)
-          if (m == rl) j = jm[r][m];
-      }
-      val[c][r] = jc.rsrc[c][j];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < kColLoop; ++c) {
-    if (c >= jc.n) continue;
-    if (wide) {
-      *reinterpret_cast<ulonglong2 *>(jc.out[c] + i0) = make_ulonglong2(val[c][0], val[c][1]);
-      *reinterpret_cast<ulonglong2 *>(jc.out[c] + i0 + 2) = make_ulonglong2(val[c][2], val[c][3]);
-      if (jc.out_valid[c])
-        *reinterpret_cast<uchar4 *>(jc.out_valid[c] + i0) =
-            make_uchar4((okbits[0] >> c) & 1u, (okbits[1] >> c) & 1u, (okbits[2] >> c) & 1u, (okbits[3] >> c) & 1u);
-    } else {
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = c0 + cc;
 #pragma unroll
       for (int r = 0; r < SJ_ROWS; ++r) {
-        if (r >= nrow) continue;
-        jc.out[c][i0 + r] = val[c][r];
-        if (jc.out_valid[c]) jc.out_valid[c][i0 + r] = (uint8_t)((okbits[r] >> c) & 1u);
+        val[cc][r] = 0;
+        if (c >= jc.n || !((okbits[r] >> c) & 1u)) continue;
+        if (c == jc.ts_col) { val[cc][r] = (uint64_t)tjoin[r]; continue; }
+        int32_t j = jrow[r];
+        const int rl = jc.rule[c];
+        if (rl >= 0) {
+#pragma unroll
+          for (int m = 0; m < kMaskLoop; ++m)
+            if (m == rl) j = jm[r][m];
+        }
+        val[cc][r] = jc.rsrc[c][j];
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = c0 + cc;
+      if (c >= jc.n) continue;
+      if (wide) {
+        sj_store64(jc.out[c] + i0, val[cc]);
+        if (jc.out_valid[c]) {
+          uint8_t ok[SJ_ROWS];
+#pragma unroll
+          for (int r = 0; r < SJ_ROWS; ++r) ok[r] = (uint8_t)((okbits[r] >> c) & 1u);
+          sj_store8(jc.out_valid[c] + i0, ok);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < SJ_ROWS; ++r) {
+          if (r >= nrow) continue;
+          jc.out[c][i0 + r] = val[cc][r];
+          if (jc.out_valid[c]) jc.out_valid[c][i0 + r] = (uint8_t)((okbits[r] >> c) & 1u);
+        }
       }
     }
   }
+  SJTICK();  // 5: joined values read and written
+#ifdef SJ_TIMING
+  if (tid == 0 && (blockIdx.x % 49999) == 777)
+    printf("SJ block %d len %d: left+carry %lld stage %lld prefix %lld search %lld emit %lld\n", (int)blockIdx.x,
+           (int)(bhi - blo), tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4]);
+#endif
   // one flag per rule; a wave raises it only while it still reads as clear
   const bool lane0 = lane == 0;
   if (__any(miss_row) && lane0 && __atomic_load_n(&out_missing[0], __ATOMIC_RELAXED) == 0) atomicOr(&out_missing[0], 1);
@@ -494,6 +594,7 @@ int asof_sorted_join(const tmp_asof_args *a, const SkewParams &sp, int64_t *boun
   }
   SjCols jc;
   memset(&jc, 0, sizeof(jc));
+  jc.ts_col = -1;
   if (a->sorted_output) {
     jc.n_left = a->n_left_cols;
     for (int c = 0; c < a->n_left_cols; ++c) {
@@ -510,6 +611,7 @@ int asof_sorted_join(const tmp_asof_args *a, const SkewParams &sp, int64_t *boun
       jc.out_valid[c] = a->out_right_valid[c];
       jc.rule[c] = (int8_t)a->right_col_rule[c];
       jc.vmask[c] = (int8_t)a->right_col_valid[c];
+      if (jc.ts_col < 0 && a->right_cols[c] == (const void *)a->ts_right && jc.rule[c] < 0) jc.ts_col = c;
     }
   }
   const SjGeom g = sj_geom(a->n_right);
@@ -523,21 +625,27 @@ int asof_sorted_join(const tmp_asof_args *a, const SkewParams &sp, int64_t *boun
   // 16-byte accesses to the left table's columns and to the joined table need every one of those
   // columns aligned for them (any allocation is; a view that starts inside one may not be)
   uintptr_t a16 = (uintptr_t)s.key_l | (uintptr_t)s.ts_l, a4 = 0;
-  if (a->sorted_output) a16 |= (uintptr_t)a->out_perm | (uintptr_t)a->out_key | (uintptr_t)a->out_ts;
-  for (int c = 0; c < jc.n_left; ++c) a16 |= (uintptr_t)jc.lsrc[c] | (uintptr_t)jc.lout[c];
+  const int by_ref = a->sorted_output && a->left_in_place != nullptr;
+  if (a->sorted_output && !by_ref) a16 |= (uintptr_t)a->out_perm | (uintptr_t)a->out_key | (uintptr_t)a->out_ts;
+  for (int c = 0; c < (by_ref ? 0 : jc.n_left); ++c) a16 |= (uintptr_t)jc.lsrc[c] | (uintptr_t)jc.lout[c];
   for (int c = 0; c < jc.n; ++c) { a16 |= (uintptr_t)jc.out[c]; a4 |= (uintptr_t)jc.out_valid[c]; }
   const int vec = (a16 & 15) == 0 && (a4 & 3) == 0 && !getenv("TEMPO_SORTED_JOIN_SCALAR");
+  if (by_ref) *a->left_in_place = 1;
   TMP_LAUNCH(sj_bounds_kernel, dim3((unsigned)((n_blocks + 1 + kBlock - 1) / kBlock)), dim3(kBlock), st, s, n_blocks, bounds);
   {
     ProfScope ps("sj_merge_kernel", st);
-    if (jc.n <= 4 && a->n_masks <= 4)
+    if (jc.n <= 4 && a->n_masks <= 2)
+      hipLaunchKernelGGL((sj_merge_kernel<4, 2>), dim3((unsigned)n_blocks), dim3(SJ_THREADS), 0, st, s, mk, sp, jc, bounds,
+                         tile_table, g.n_tiles, a->out_idx, a->out_missing, a->sorted_output, a->out_perm, a->out_key,
+                         a->out_ts, vec, by_ref);
+    else if (jc.n <= 4 && a->n_masks <= 4)
       hipLaunchKernelGGL((sj_merge_kernel<4, 4>), dim3((unsigned)n_blocks), dim3(SJ_THREADS), 0, st, s, mk, sp, jc, bounds,
                          tile_table, g.n_tiles, a->out_idx, a->out_missing, a->sorted_output, a->out_perm, a->out_key,
-                         a->out_ts, vec);
+                         a->out_ts, vec, by_ref);
     else
       hipLaunchKernelGGL((sj_merge_kernel<0, 0>), dim3((unsigned)n_blocks), dim3(SJ_THREADS), 0, st, s, mk, sp, jc, bounds,
                          tile_table, g.n_tiles, a->out_idx, a->out_missing, a->sorted_output, a->out_perm, a->out_key,
-                         a->out_ts, vec);
+                         a->out_ts, vec, by_ref);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

@@ -403,11 +403,7 @@ static int slice_args(const tmp_partition_args *a, SliceArgs *out) {
                 "partition: sliced keys need ts_partition_val > 0 and bracket_count >= 1");
     TMP_REQUIRE(!a->halo || a->n_parts <= 255, TMP_EINVAL, "partition: halo mode takes at most 255 parts");
     sl.ts = a->ts;
-    sl.sp.enabled = 1;
-    sl.sp.v_is_int = a->v_is_int;
-    sl.sp.ts_is_seconds = a->ts_is_seconds;
-    sl.sp.v = a->ts_partition_val;
-    sl.sp.one_minus_fraction = a->one_minus_fraction;
+    skew_params_set(&sl.sp, 1, a->v_is_int, a->ts_is_seconds, a->ts_partition_val, a->one_minus_fraction);
     sl.bracket_min = a->bracket_min;
     sl.bracket_count = a->bracket_count;
     sl.n_split = (uint32_t)a->n_split;

@@ -162,12 +162,17 @@ def _same_mask_key(m):
 
 def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
                     skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
-                    ts_partition_val=None, fraction=0.5):
+                    ts_partition_val=None, fraction=0.5, left_by_reference=False):
     """Fused AS-OF join; a table too wide for one sort word is joined one half of the key
-    dictionary at a time and the halves are concatenated (key order is row order)."""
+    dictionary at a time and the halves are concatenated (key order is row order).
+
+    left_by_reference=True: when the left table turns out to be in (key, ts) order already, row p of
+    the result is left row p and nothing of the left table is copied -- the result then has
+    in_place=True, perm=None, and key / ts / left are the caller's own tensors."""
     try:
         return _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
-                                     skip_nulls, seq_r, seq_r_valid, ts_is_seconds, ts_partition_val, fraction)
+                                     skip_nulls, seq_r, seq_r_valid, ts_is_seconds, ts_partition_val, fraction,
+                                     left_by_reference)
     except NotImplementedError as err:
         if not _too_wide(err) or key_l is None or n_keys < 2:
             raise
@@ -190,12 +195,12 @@ def asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, rig
     return dict(perm=torch.cat([a["perm"], b["perm"]]), key=torch.cat([a["key"], b["key"]]),
                 ts=torch.cat([a["ts"], b["ts"]]), left=[torch.cat(p) for p in zip(a["left"], b["left"])],
                 right=[(torch.cat([x[0], y[0]]), torch.cat([x[1], y[1]])) for x, y in zip(a["right"], b["right"])],
-                missing=a["missing"] | b["missing"], mask_of=a["mask_of"])
+                missing=a["missing"] | b["missing"], mask_of=a["mask_of"], in_place=False)
 
 
 def _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_cols, right_col_masks,
                           skip_nulls=True, seq_r=None, seq_r_valid=None, ts_is_seconds=False,
-                          ts_partition_val=None, fraction=0.5):
+                          ts_partition_val=None, fraction=0.5, left_by_reference=False):
     """Fused AS-OF join: the joined table itself, in (key, ts) order, written with streaming
     accesses only (the payload columns ride along with the last radix pass of their table).
 
@@ -264,10 +269,16 @@ def _asof_join_table_once(key_l, ts_l, key_r, ts_r, n_keys, left_cols, right_col
     a.n_left_cols, a.left_cols, a.out_left_cols = len(left_cols), keep[0], keep[1]
     a.n_right_cols, a.right_cols, a.out_right_cols, a.out_right_valid = len(right_cols), keep[2], keep[3], keep[4]
     a.right_col_rule, a.right_col_valid = keep[5], keep[6]
+    in_place = C.c_int32(0)
+    if left_by_reference:
+        a.left_in_place = C.pointer(in_place)
     ws = _workspace(lib().tmp_asof_join_workspace_bytes(C.byref(a)), dev)
     check(lib().tmp_asof_join(C.byref(a), ws.data_ptr(), ws.numel(), _stream()), "tmp_asof_join")
+    if in_place.value:  # the left table was in order: its own columns are the result's
+        perm, ts_s, out_left = None, ts_l, list(left_cols)
+        key_s = key_l if key_l is not None else key_s.zero_()
     return dict(perm=perm, key=key_s, ts=ts_s, left=out_left, right=list(zip(out_right, out_valid)),
-                missing=missing, mask_of=mask_of)
+                missing=missing, mask_of=mask_of, in_place=bool(in_place.value))
 
 
 def gather(src, idx, src_valid=None, want_valid=True):

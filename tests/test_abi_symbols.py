@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(handle, name), f"{name} is declared in tempo_hip.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes signature in tempo_amd/_lib.py"
-    assert handle.tmp_abi_version() == 1
+    assert handle.tmp_abi_version() == 2
 
 
 def test_argument_errors_need_no_gpu():

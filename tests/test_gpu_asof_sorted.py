@@ -179,3 +179,28 @@ def test_sorted_join_columns_that_start_inside_an_allocation(orc, ops):
         vals, valid = out["right"][c]
         assert np.array_equal(valid.cpu().numpy().astype(bool), j >= 0), c
         assert np.array_equal(vals.cpu().numpy(), np.where(j >= 0, src[np.clip(j, 0, None)], 0)), c
+
+
+def test_sorted_join_left_table_by_reference(orc, ops):
+    """left_by_reference: a left table in order is not copied -- the result names the caller's own
+    key / ts / payload tensors and the same joined columns; a left table out of order is ordered
+    and copied as ever."""
+    rng = np.random.default_rng(21)
+    nL, nR, nk = 80_000, 60_000, 13
+    key_l, ts_l, key_r, ts_r, _, _, masks = _sorted_tables(rng, nL, nR, nk, 900 * 1_000_000, 1000, 1, 0.2, False)
+    pr, bid = rng.normal(100, 1, nL), rng.normal(99, 1, nR)
+    dk, dt, dp = _dev(key_l), _dev(ts_l), _dev(pr)
+    args = (_dev(key_r), _dev(ts_r), nk, [dp], [_dev(ts_r), _dev(bid)], [None, _dev(masks[0])])
+    ref = ops.asof_join_table(dk, dt, *args)
+    out = ops.asof_join_table(dk, dt, *args, left_by_reference=True)
+    assert out["in_place"] and out["perm"] is None and not ref["in_place"]
+    assert out["key"] is dk and out["ts"] is dt and out["left"][0] is dp
+    for c in range(2):
+        assert torch.equal(out["right"][c][0], ref["right"][c][0]) and torch.equal(out["right"][c][1], ref["right"][c][1])
+    assert torch.equal(out["missing"], ref["missing"])
+    o = rng.permutation(nL)
+    out = ops.asof_join_table(_dev(key_l[o]), _dev(ts_l[o]), *args[:3], [_dev(pr[o])], *args[4:], left_by_reference=True)
+    assert not out["in_place"]
+    assert torch.equal(out["key"], ref["key"]) and torch.equal(out["ts"], ref["ts"])
+    for c in range(2):
+        assert torch.equal(out["right"][c][1], ref["right"][c][1])

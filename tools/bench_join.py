@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--order", choices=["random", "sorted", "time"], default="random",
                     help="row order of both sides: as generated (random), by (key, ts), or by ts alone")
     ap.add_argument("--no-skew", action="store_true", help="plain join: no tsPartitionVal brackets")
+    ap.add_argument("--copy-left", action="store_true",
+                    help="have the join write key / ts / left payload of the result even when the left table is "
+                         "in order already (default: such a table is used by reference)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = args.rows // 2
@@ -43,9 +46,10 @@ def main():
     def run():
         return ops.asof_join_table(q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], 10_000, [q["trade_pr"]],
                                    [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
-                                   skip_nulls=True, ts_partition_val=None if args.no_skew else 10, fraction=0.1)
+                                   skip_nulls=True, ts_partition_val=None if args.no_skew else 10, fraction=0.1,
+                                   left_by_reference=not args.copy_left)
 
-    run()
+    in_place = run()["in_place"]
     torch.cuda.synchronize()
     _lib.profile_reset()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -61,7 +65,7 @@ def main():
             k = kern.setdefault(name, [0, 0.0])
             k[0] += 1
             k[1] += ms / args.reps
-    print(json.dumps(dict(rows=args.rows, order=args.order, ms_per_call=round(e0.elapsed_time(e1) / args.reps, 3),
+    print(json.dumps(dict(rows=args.rows, order=args.order, left_in_place=in_place, ms_per_call=round(e0.elapsed_time(e1) / args.reps, 3),
                           kernels={k: dict(launches=v[0] // args.reps, ms=round(v[1], 3))
                                    for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])})))
 
