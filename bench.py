@@ -381,6 +381,35 @@ def main():
         shuffled_ms = (time.perf_counter() - t1) / 2 * 1e3
         del ts_p
 
+    # ---- the same join on the same tables laid out in (key, ts) order (not part of `value`): what
+    # the operator costs when its input arrives ordered, as it does from an upstream window operator --
+    # one sweep over the columns, the left table used by reference
+    sorted_ms = None
+    if rank == 0 and args.gpus == 1 and not args.no_shuffled:
+        sq = {}
+        for side, cols in (("l", ["key_l", "ts_l", "trade_pr"]),
+                           ("r", ["key_r", "ts_r", "bid", "ask", "bid_valid", "ask_valid"])):
+            o = torch.argsort(tq["ts_" + side], stable=True)
+            o = o[torch.argsort(tq["key_" + side][o], stable=True)]
+            for c in cols:
+                sq[c] = tq[c][o].contiguous()
+            del o
+
+        def sorted_join():
+            return ops.asof_join_table(sq["key_l"], sq["ts_l"], sq["key_r"], sq["ts_r"], ASOF_KEYS, [sq["trade_pr"]],
+                                       [sq["ts_r"], sq["bid"], sq["ask"]], [None, sq["bid_valid"], sq["ask_valid"]],
+                                       skip_nulls=True, ts_partition_val=10, fraction=0.1, left_by_reference=True)
+
+        sorted_join()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            sorted_join()
+        e1.record()
+        torch.cuda.synchronize()
+        sorted_ms = e0.elapsed_time(e1) / 3
+        del sq
+
     # ---- CPU baseline: the C oracle (a port of the reference plan) on a bounded sample, 1 core
     cpu = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
@@ -426,6 +455,7 @@ def main():
                 "rccl_ranks": rccl_ranks,
                 "rows_held_per_rank": rows_per_rank,
                 "range_stats_shuffled_ms_per_step": None if shuffled_ms is None else round(shuffled_ms, 3),
+                "asof_sorted_input_ms_per_step": None if sorted_ms is None else round(sorted_ms, 3),
                 "peak_hbm_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),

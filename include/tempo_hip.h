@@ -233,6 +233,43 @@ size_t tmp_range_stats_wide_workspace_bytes(const tmp_range_stats_args *a);
 int tmp_range_stats(const tmp_range_stats_args *a, void *workspace, size_t workspace_bytes,
                     void *stream);
 
+/* withRangeStats over several metric columns of one table (python/tempo/tsdf.py:707-717: the
+ * reference appends six aggregates per column of colsToSummarize over ONE window): the rows are
+ * ordered once, with every column travelling along, and each column's statistics are then written
+ * from that order.  Same results, column by column, as tmp_range_stats on that column alone.
+ * x, x_valid, x_is_i64 and the out_* members are HOST arrays of n_cols entries (1 <= n_cols <=
+ * TMP_MAX_STATS_COLS); x_valid entries may be NULL; out_min / out_max / out_sum entries point to
+ * double or int64 arrays as x_is_i64 says.  out_perm is shared: out_perm[p] = input row at output
+ * position p.  Workspace rule as for tmp_range_stats (plain size: TMP_EWIDE when some frame leaves
+ * the on-chip region; wide size: every frame length). */
+#define TMP_MAX_STATS_COLS 4
+typedef struct {
+  int64_t n;
+  const int32_t *key;
+  int32_t n_keys;
+  const int64_t *ts;
+  int32_t ts_is_seconds;
+  int64_t range_back_secs;
+  int32_t n_cols;
+  const void *const *x;
+  const uint8_t *const *x_valid;
+  const int32_t *x_is_i64;
+  int32_t *out_perm;
+  double *const *out_mean;
+  int64_t *const *out_count;
+  void *const *out_min;
+  void *const *out_max;
+  void *const *out_sum;
+  double *const *out_stddev;
+  double *const *out_zscore;
+  uint8_t *const *out_valid;
+} tmp_range_stats_cols_args;
+size_t tmp_range_stats_cols_workspace_bytes(const tmp_range_stats_cols_args *a);
+size_t tmp_range_stats_cols_wide_workspace_bytes(const tmp_range_stats_cols_args *a);
+int tmp_range_stats_cols(const tmp_range_stats_cols_args *a, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+
 /* ---------------------------------------------------------------------------------------
  * EMA: fixed-tap FIR over the previous rows of the same series.
  *

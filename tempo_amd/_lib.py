@@ -52,6 +52,18 @@ class RangeStatsArgs(C.Structure):
                 ("any_order", C.c_int32)]
 
 
+TMP_MAX_STATS_COLS = 4
+
+
+class RangeStatsColsArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
+                ("ts_is_seconds", C.c_int32), ("range_back_secs", C.c_int64), ("n_cols", C.c_int32),
+                ("x", C.POINTER(_vp)), ("x_valid", C.POINTER(_vp)), ("x_is_i64", C.POINTER(C.c_int32)),
+                ("out_perm", _vp), ("out_mean", C.POINTER(_vp)), ("out_count", C.POINTER(_vp)),
+                ("out_min", C.POINTER(_vp)), ("out_max", C.POINTER(_vp)), ("out_sum", C.POINTER(_vp)),
+                ("out_stddev", C.POINTER(_vp)), ("out_zscore", C.POINTER(_vp)), ("out_valid", C.POINTER(_vp))]
+
+
 class EmaArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
                 ("ts_is_seconds", C.c_int32), ("seq", _vp), ("seq_valid", _vp), ("x", _vp),
@@ -153,6 +165,9 @@ SYMBOLS = {
     "tmp_range_stats_workspace_bytes": _WS(RangeStatsArgs),
     "tmp_range_stats_wide_workspace_bytes": _WS(RangeStatsArgs),
     "tmp_range_stats": _OP(RangeStatsArgs),
+    "tmp_range_stats_cols_workspace_bytes": _WS(RangeStatsColsArgs),
+    "tmp_range_stats_cols_wide_workspace_bytes": _WS(RangeStatsColsArgs),
+    "tmp_range_stats_cols": _OP(RangeStatsColsArgs),
     "tmp_ema_workspace_bytes": _WS(EmaArgs),
     "tmp_ema": _OP(EmaArgs),
     "tmp_lookback_workspace_bytes": _WS(LookbackArgs),

@@ -125,11 +125,16 @@ __device__ __forceinline__ void slot_add_f64(double v, double pivot, double &sd,
   mx = MinMax<double>::mx(mx, v);
 }
 
+__device__ __forceinline__ constexpr int xi(int e) { return e + e / RK_SB; }
+
 template <typename T>
 struct RsShared {
   static constexpr bool kIntT = ((T)0.5 == (T)0);
   uint32_t ck[RK_CAP];       // ((sort word >> low) - base, saturated) << 1 | metric-not-NULL
-  T x[RK_CAP];               // metric; for double a NULL slot holds NaN
+  // metric; for double a NULL slot holds NaN.  Slot e lives at xi(e): one spare element after every
+  // sub-block, so that the threads that each add up one sub-block (lane stride = a sub-block) read
+  // from distinct banks -- with the sub-blocks back to back sixteen lanes share a bank
+  T x[RK_CAP + RK_NSB];
   double bs[RK_NSB + 1];     // exclusive prefix over sub-blocks of sum(x - pivot)
   double bq[RK_NSB + 1];     // ... of sum((x - pivot)^2)
   uint64_t bi[kIntT ? RK_NSB + 1 : 1];  // ... of the exact integer sum (int64 metrics)
@@ -209,14 +214,14 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       if (e < len) {
         const uint64_t word = wd[r];
         uint64_t rel = (word >> low) - base;
-        ok[r] = (word & 1ull) != 0;
+        ok[r] = ((word >> o.vbit) & 1ull) != 0;
         c = (uint32_t)(rel < RK_SAT ? rel : RK_SAT) << 1 | (ok[r] ? 1u : 0u);
         fin[r] = ok[r] && Ord<T>::finite(xv[r]);
         if (ok[r] && !fin[r]) s.nonfinite = 1;
       }
       if (!ok[r]) xv[r] = MinMax<T>::null_slot();
       s.ck[e] = c;
-      s.x[e] = xv[r];
+      s.x[xi(e)] = xv[r];
       // pivot = first finite value of the region: one LDS atomic per wave, not per slot
       uint64_t bal = __ballot(fin[r]);
       if (bal && lane == 0) atomicMin(&s.pivot_at, e + (int)__ffsll((long long)bal) - 1);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   __syncthreads();
   RTICK();
   const int pat = s.pivot_at;
-  const double pivot = pat < RK_CAP ? (double)s.x[pat] : 0.0;
+  const double pivot = pat < RK_CAP ? (double)s.x[xi(pat)] : 0.0;
 
   // first slot at or after the frame start of the row whose relative sort word is krel, searched
   // in slots [lo, hi]; the row's full word is base + krel (rows with a saturated krel are deferred)
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     }
 #pragma unroll
     for (int j = 0; j < RK_SB; ++j) {
-      const T v = s.x[b * RK_SB + j];
+      const T v = s.x[b * (RK_SB + 1) + j];
       const bool okj = (cs[j] & 1u) != 0;
       const bool finj = okj && Ord<T>::finite(v);
       const double d = finj ? (double)v - pivot : 0.0;
@@ -435,14 +440,14 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     if constexpr (!kInt) {
       if (!s.nonfinite) {
       // every staged value is finite and NULL slots hold NaN: no per-slot tests needed
-      for (int e = a; e <= head_end; ++e) slot_add_f64(s.x[e], pivot, sd, sq, dc, mn, mx);
-      for (int e = tail_begin; e <= b; ++e) slot_add_f64(s.x[e], pivot, sd, sq, dc, mn, mx);
+      for (int e = a; e <= head_end; ++e) slot_add_f64(s.x[xi(e)], pivot, sd, sq, dc, mn, mx);
+      for (int e = tail_begin; e <= b; ++e) slot_add_f64(s.x[xi(e)], pivot, sd, sq, dc, mn, mx);
       }
     }
     if (kInt || s.nonfinite) {
       for (int e = a; e <= b; e = (e == head_end ? tail_begin : e + 1)) {
         if (s.ck[e] & 1u) {
-          T v = s.x[e];
+          T v = s.x[xi(e)];
           if (Ord<T>::finite(v)) {
             double d = (double)v - pivot;
             sd += d;
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       double acc = 0.0, lin = 0.0;
       for (int e = a; e <= b; ++e) {
         if (s.ck[e] & 1u) {
-          double dv = (double)s.x[e] - mean;
+          double dv = (double)s.x[xi(e)] - mean;
           acc += dv * dv;
           lin += dv;
         }
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     o.sum[i] = okk ? sum : (T)0;
     o.stddev[i] = sd_ok ? stddev : 0.0;
     const bool z_ok = (cki & 1u) && sd_ok && stddev != 0.0;  // Spark Divide: NULL on a zero divisor
-    o.zscore[i] = z_ok ? ((double)s.x[li] - mean) * fast_rcp(stddev) : 0.0;
+    o.zscore[i] = z_ok ? ((double)s.x[xi(li)] - mean) * fast_rcp(stddev) : 0.0;
     o.valid[i] = (uint8_t)((okk ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
   }
 #ifdef RK_TIMING
@@ -586,6 +591,29 @@ static void rs_spec(const tmp_range_stats_args *a, OrderSpec *s) {
   s->masks[0] = a->x_valid;  // NULL pointer = every row valid
 }
 
+// One metric column in sorted order -> its seven output columns: the region kernel, then (when some
+// frame left a block's region, which costs one small blocking read to learn) the wide path.
+template <typename T>
+static int rs_column(const OrderResult &res, const T *xs, int64_t n, const Layout &lay, uint64_t w, const RsOut<T> &o,
+                     int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st) {
+  const int n_tiles = (int)((n + RK_ROWS - 1) / RK_ROWS);
+  int grid = (n_tiles + 7) / 8 * 8;
+  TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
+  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm, xs, n, lay, w, o,
+             deferred_flag, n_tiles);
+  TMP_CHECK_HIP(hipGetLastError());
+  int32_t deferred = 0;
+  TMP_CHECK_HIP(hipMemcpyAsync(&deferred, deferred_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  TMP_CHECK_HIP(hipStreamSynchronize(st));
+  if (!deferred) return TMP_OK;
+  if (!have_wide) {
+    set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
+              "tmp_range_stats_wide_workspace_bytes() bytes");
+    return TMP_EWIDE;
+  }
+  return rs_wide_run<T>(res.comp, xs, n, lay, w, o, wide, st);
+}
+
 template <typename T>
 static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipStream_t st,
                   const RangeInfo *known = nullptr) {
@@ -612,23 +640,27 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
-  const int n_tiles = (int)((a->n + RK_ROWS - 1) / RK_ROWS);
-  int grid = (n_tiles + 7) / 8 * 8;
-  TMP_CHECK_HIP(hipMemsetAsync(p.deferred, 0, sizeof(int32_t), st));
-  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm,
-                     xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred, n_tiles);
-  TMP_CHECK_HIP(hipGetLastError());
-  // one small blocking read: did any frame leave its block's region?
-  int32_t deferred = 0;
-  TMP_CHECK_HIP(hipMemcpyAsync(&deferred, p.deferred, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  TMP_CHECK_HIP(hipStreamSynchronize(st));
-  if (!deferred) return TMP_OK;
-  if (!have_wide) {
-    set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
-              "tmp_range_stats_wide_workspace_bytes() bytes");
-    return TMP_EWIDE;
-  }
-  return rs_wide_run<T>(res.comp, xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.wide, st);
+  o.vbit = 0;
+  return rs_column<T>(res, xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
+}
+
+// Several metric columns over one ordering (tmp_range_stats_cols).
+struct RsColsPlan {
+  OrderBuffers ob;
+  uint64_t *xs[TMP_MAX_STATS_COLS];
+  int32_t *deferred;
+  RsWidePlan wide;
+};
+
+static void rs_cols_plan(const tmp_range_stats_cols_args *a, Workspace &ws, RsColsPlan *p, bool with_wide) {
+  const int nc = a->n_cols < 1 ? 1 : (a->n_cols > TMP_MAX_STATS_COLS ? TMP_MAX_STATS_COLS : a->n_cols);
+  order_plan(a->n, ws, &p->ob, plan_keys(a->key, a->n_keys), nc);
+  for (int c = 0; c < TMP_MAX_STATS_COLS; ++c)
+    p->xs[c] = c < nc ? ws.take<uint64_t>((size_t)(a->n > 0 ? a->n : 1)) : nullptr;
+  p->deferred = ws.take<int32_t>(1);
+  bool any_i64 = false;
+  for (int c = 0; c < nc; ++c) any_i64 = any_i64 || (a->x_is_i64 && a->x_is_i64[c]);
+  if (with_wide) rs_wide_plan(a->n, any_i64, ws, &p->wide);  // one set of buffers, used column after column
 }
 
 }  // namespace tmp
@@ -682,4 +714,85 @@ extern "C" int tmp_range_stats(const tmp_range_stats_args *a, void *workspace,
     if (done) return TMP_OK;
   }
   return a->x_is_i64 ? rs_run<int64_t>(a, p, have_wide, st, known) : rs_run<double>(a, p, have_wide, st, known);
+}
+
+extern "C" size_t tmp_range_stats_cols_workspace_bytes(const tmp_range_stats_cols_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  RsColsPlan p;
+  rs_cols_plan(a, ws, &p, false);
+  return ws.off;
+}
+
+extern "C" size_t tmp_range_stats_cols_wide_workspace_bytes(const tmp_range_stats_cols_args *a) {
+  if (!a) return 0;
+  Workspace ws(nullptr, 0);
+  RsColsPlan p;
+  rs_cols_plan(a, ws, &p, true);
+  return ws.off;
+}
+
+extern "C" int tmp_range_stats_cols(const tmp_range_stats_cols_args *a, void *workspace, size_t workspace_bytes,
+                                    void *stream) {
+  clear_error();
+  TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_range_stats_cols: null args");
+  TMP_REQUIRE(a->n >= 0 && a->n < (1ll << 31), TMP_EINVAL, "tmp_range_stats_cols: row count must be in [0, 2^31)");
+  TMP_REQUIRE(a->range_back_secs >= 0, TMP_EINVAL, "tmp_range_stats_cols: range_back_secs must be >= 0");
+  TMP_REQUIRE(a->n_cols >= 1 && a->n_cols <= TMP_MAX_STATS_COLS, TMP_EINVAL,
+              "tmp_range_stats_cols: n_cols must be in [1, %d]", TMP_MAX_STATS_COLS);
+  if (a->n == 0) return TMP_OK;
+  TMP_REQUIRE(a->ts && a->x && a->x_valid && a->x_is_i64 && a->out_perm && a->out_mean && a->out_count && a->out_min &&
+                  a->out_max && a->out_sum && a->out_stddev && a->out_zscore && a->out_valid,
+              TMP_EINVAL, "tmp_range_stats_cols: null pointer");
+  for (int c = 0; c < a->n_cols; ++c)
+    TMP_REQUIRE(a->x[c] && a->out_mean[c] && a->out_count[c] && a->out_min[c] && a->out_max[c] && a->out_sum[c] &&
+                    a->out_stddev[c] && a->out_zscore[c] && a->out_valid[c],
+                TMP_EINVAL, "tmp_range_stats_cols: column %d has a null pointer", c);
+  const bool have_wide = workspace_bytes >= tmp_range_stats_cols_wide_workspace_bytes(a);
+  Workspace ws(workspace, workspace_bytes);
+  RsColsPlan p;
+  rs_cols_plan(a, ws, &p, have_wide);
+  TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_range_stats_cols: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  // one ordering for all columns: column c's "not NULL" flag rides in bit c of the sort words and
+  // its values travel with the rows
+  OrderSpec s;
+  memset(&s, 0, sizeof(s));
+  s.n = a->n; s.key = a->key; s.n_keys = a->n_keys; s.ts = a->ts;
+  s.prim_div = a->ts_is_seconds ? 1 : 1000000;
+  s.n_masks = a->n_cols;
+  for (int c = 0; c < a->n_cols; ++c) s.masks[c] = a->x_valid[c];
+  RangeInfo r;
+  TMP_TRY(order_scan_ranges(s, p.ob, st));
+  TMP_TRY(order_read_ranges(p.ob, &r, st));
+  Layout lay;
+  TMP_TRY(order_make_layout(s, r, a->n_cols, &lay));
+  OrderResult res;
+  bool carried = false;
+  const uint64_t *pay_src[TMP_MAX_STATS_COLS];
+  for (int c = 0; c < a->n_cols; ++c) pay_src[c] = (const uint64_t *)a->x[c];
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, a->n_cols, pay_src, p.xs, &carried));
+  for (int c = 0; c < a->n_cols; ++c) {
+    const void *xs = carried ? (const void *)p.xs[c] : a->x[c];
+    int rc;
+    if (a->x_is_i64[c]) {
+      RsOut<int64_t> o;
+      o.perm = a->out_perm; o.mean = a->out_mean[c]; o.count = a->out_count[c];
+      o.mn = (int64_t *)a->out_min[c]; o.mx = (int64_t *)a->out_max[c]; o.sum = (int64_t *)a->out_sum[c];
+      o.stddev = a->out_stddev[c]; o.zscore = a->out_zscore[c]; o.valid = a->out_valid[c];
+      o.vbit = c;
+      rc = rs_column<int64_t>(res, (const int64_t *)xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred,
+                              have_wide, p.wide, st);
+    } else {
+      RsOut<double> o;
+      o.perm = a->out_perm; o.mean = a->out_mean[c]; o.count = a->out_count[c];
+      o.mn = (double *)a->out_min[c]; o.mx = (double *)a->out_max[c]; o.sum = (double *)a->out_sum[c];
+      o.stddev = a->out_stddev[c]; o.zscore = a->out_zscore[c]; o.valid = a->out_valid[c];
+      o.vbit = c;
+      rc = rs_column<double>(res, (const double *)xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred,
+                             have_wide, p.wide, st);
+    }
+    TMP_TRY(rc);
+  }
+  return TMP_OK;
 }

@@ -238,6 +238,7 @@ int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo 
   o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
   o.mn = (double *)a->out_min; o.mx = (double *)a->out_max; o.sum = (double *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
+  o.vbit = 0;
   TMP_LAUNCH(cell_rows_kernel, dim3(grid_for(a->n, kBlock * 4, 1 << 20)), dim3(kBlock), st, a->key, a->ts,
              (const double *)a->x, a->x_valid, a->n, sec_div, r.prim_min, (int64_t)per_key, blk, w, nk, pre, suf, o);
   TMP_CHECK_HIP(hipGetLastError());

@@ -37,6 +37,7 @@ struct RsOut {
   double *stddev;
   double *zscore;
   uint8_t *valid;
+  int vbit;  // bit of the sort words that holds this metric's "not NULL" flag
 };
 
 template <typename T>
@@ -65,7 +66,7 @@ __device__ void rs_row_serial(const uint64_t *comp, const T *xs, int64_t lo, int
   double dsum = 0.0, avg = 0.0, m2 = 0.0, nn = 0.0;
   uint64_t isum = 0;
   for (int64_t j = lo; j <= hi; ++j) {
-    if (!(comp[j] & 1ull)) continue;
+    if (!((comp[j] >> o.vbit) & 1ull)) continue;
     T v = xs[j];
     if (n == 0) { mn = v; mx = v; }
     else {
@@ -84,7 +85,7 @@ __device__ void rs_row_serial(const uint64_t *comp, const T *xs, int64_t lo, int
   }
   T sum;
   if constexpr (sizeof(T) == 8 && ((T)0.5 == (T)0)) sum = (T)isum; else sum = (T)dsum;
-  bool x_ok = (comp[i] & 1ull) != 0;
+  bool x_ok = ((comp[i] >> o.vbit) & 1ull) != 0;
   rs_store<T>(o, i, n, n ? dsum / (double)n : 0.0, mn, mx, sum, n > 1,
               n > 1 ? sqrt(m2 / (nn - 1.0)) : 0.0, x_ok, (double)xs[i]);
 }

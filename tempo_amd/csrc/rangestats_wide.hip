@@ -81,7 +81,7 @@ void rs_wide_plan(int64_t n, bool is_i64, Workspace &ws, RsWidePlan *p) {
 // themselves, and with them the variance of values far from 0, to cancellation.
 template <typename T>
 __global__ __launch_bounds__(256) void wide_pivot_kernel(const uint64_t *comp, const T *xs, int64_t n,
-                                                         int64_t supers, double *pivot) {
+                                                         int64_t supers, double *pivot, int vbit) {
   int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (s >= supers) return;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void wide_pivot_kernel(const uint64_t *comp, c
     if (base + (int64_t)r * 64 >= n) break;
     bool ok = false;
     T v = (T)0;
-    if (i < n && (comp[i] & 1ull)) {
+    if (i < n && ((comp[i] >> vbit) & 1ull)) {
       v = xs[i];
       ok = Ord<T>::finite(v);
     }
@@ -130,7 +130,7 @@ __device__ __forceinline__ V block_scan(V v, Op op, V *lds) {
 
 template <typename T>
 __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *comp, const T *xs, int64_t n,
-                                                              RsWidePlan p) {
+                                                              RsWidePlan p, int vbit) {
   using W = WideOps<T>;
   __shared__ double lds_d[16];
   __shared__ uint64_t lds_u[16];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *co
   const bool in = i < n;
   bool ok = false, fin = false;
   T v = (T)0;
-  if (in && (comp[i] & 1ull)) {
+  if (in && ((comp[i] >> vbit) & 1ull)) {
     ok = true;
     v = xs[i];
     fin = Ord<T>::finite(v);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
       piece_merge((double)(cnt - nonfin), s, q, p.pivot[cA / WK_SUPER], N, ref, rmean, M2, dsum);
       if (!nonfin)
         for (int64_t j = A; j <= B; ++j)
-          if (comp[j] & 1ull) { T v = xs[j]; mn = W::mn(mn, v); mx = W::mx(mx, v); }
+          if ((comp[j] >> o.vbit) & 1ull) { T v = xs[j]; mn = W::mn(mn, v); mx = W::mx(mx, v); }
     } else {
       {  // head: rows A .. end of chunk cA
         const uint64_t tc = p.tot_c[cA];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     T sum;
     if constexpr (W::kInt) sum = (T)isum;
     else sum = (T)dsum;
-    const bool x_ok = (wi & 1ull) != 0;
+    const bool x_ok = ((wi >> o.vbit) & 1ull) != 0;
     const bool same = cnt > 1 && mn == mx;  // all values identical: Spark's m2 is exactly 0
     const double sd = cnt > 1 ? (same ? 0.0 : sqrt(M2 / (N - 1.0))) : 0.0;
     rs_store<T>(o, i, (int64_t)cnt, cnt ? ref + rmean : 0.0, mn, mx, sum, cnt > 1, sd, x_ok, x_ok ? (double)xs[i] : 0.0);
@@ -332,8 +332,8 @@ template <typename T>
 int rs_wide_run(const uint64_t *comp, const T *xs, int64_t n, const Layout &lay, uint64_t w,
                 const RsOut<T> &o, RsWidePlan &p, hipStream_t st) {
   const int64_t supers = (p.chunks + WK_SUPER - 1) / WK_SUPER;
-  TMP_LAUNCH(wide_pivot_kernel<T>, dim3((unsigned)((supers + 3) / 4)), dim3(256), st, comp, xs, n, supers, p.pivot);
-  TMP_LAUNCH(wide_chunk_kernel<T>, dim3((unsigned)p.chunks), dim3(WK_CHUNK), st, comp, xs, n, p);
+  TMP_LAUNCH(wide_pivot_kernel<T>, dim3((unsigned)((supers + 3) / 4)), dim3(256), st, comp, xs, n, supers, p.pivot, o.vbit);
+  TMP_LAUNCH(wide_chunk_kernel<T>, dim3((unsigned)p.chunks), dim3(WK_CHUNK), st, comp, xs, n, p, o.vbit);
   TMP_LAUNCH(wide_super_kernel, dim3((unsigned)((supers + 3) / 4)), dim3(256), st, p, supers);
   for (int lv = 1; lv < p.levels; ++lv)
     TMP_LAUNCH(wide_table_kernel<T>, dim3(grid_for(p.chunks, 256, 4096)), dim3(256), st, p.tab_mn, p.tab_mx,

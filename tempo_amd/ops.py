@@ -325,15 +325,75 @@ def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=Fals
                        _p(x), _p(x_valid), int(range_back_secs), _p(out["perm"]), _p(out["mean"]),
                        _p(out["count"]), _p(out["min"]), _p(out["max"]), _p(out["sum"]),
                        _p(out["stddev"]), _p(out["zscore"]), _p(out["valid"]), int(bool(any_order)))
-    ws = _workspace(lib().tmp_range_stats_workspace_bytes(C.byref(a)), dev)
-    rc = lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
-    if rc == _lib.TMP_EWIDE:
-        # some frame is longer than a block's on-chip region: run again with room for the wide path
-        del ws
-        ws = _workspace(lib().tmp_range_stats_wide_workspace_bytes(C.byref(a)), dev)
-        rc = lib().tmp_range_stats(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
-    check(rc, "tmp_range_stats")
+    _run_with_wide_fallback(lib().tmp_range_stats, lib().tmp_range_stats_workspace_bytes,
+                            lib().tmp_range_stats_wide_workspace_bytes, a, n, dev, "tmp_range_stats")
     return out
+
+
+# Tables up to this many rows get the workspace of the long-frame path (about 60 bytes per row more)
+# straight away, so that their call never has to be made twice.
+WIDE_WORKSPACE_UPFRONT_ROWS = 1 << 25
+
+
+def _run_with_wide_fallback(fn, plain_bytes, wide_bytes, a, n, dev, what):
+    """Calls a range-statistics entry point.  Small tables bring the long-frame workspace along from
+    the start; a large one is first tried with the plain workspace and run again with the larger one
+    only if the library reports a frame that leaves the on-chip region (TMP_EWIDE)."""
+    upfront = n <= WIDE_WORKSPACE_UPFRONT_ROWS
+    ws = _workspace((wide_bytes if upfront else plain_bytes)(C.byref(a)), dev)
+    rc = fn(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+    if rc == _lib.TMP_EWIDE and not upfront:
+        del ws
+        ws = _workspace(wide_bytes(C.byref(a)), dev)
+        rc = fn(C.byref(a), ws.data_ptr(), ws.numel(), _stream())
+    check(rc, what)
+
+
+def range_stats_cols(key, ts, xs, xs_valid, n_keys, range_back_secs, ts_is_seconds=False):
+    """withRangeStats over several metric columns of one table (python/tempo/tsdf.py:707-717): one
+    ordering step, every column travelling with the rows, then the statistics column by column.
+    xs: float64 or int64 device columns; xs_valid: uint8 masks or None.  Returns (perm, [out dict per
+    column as range_stats gives it, without perm]).  More than _lib.TMP_MAX_STATS_COLS columns go in
+    groups of that many (each group orders the rows again)."""
+    n = ts.numel()
+    dev = ts.device
+    _dev(ts, torch.int64, "ts")
+    _dev(key, torch.int32, "key", n)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    outs = []
+    for g0 in range(0, len(xs), _lib.TMP_MAX_STATS_COLS):
+        gx, gv = xs[g0:g0 + _lib.TMP_MAX_STATS_COLS], xs_valid[g0:g0 + _lib.TMP_MAX_STATS_COLS]
+        k = len(gx)
+        is_i64, group = [], []
+        for i, (x, v) in enumerate(zip(gx, gv)):
+            i64 = x.dtype == torch.int64
+            _dev(x, torch.int64 if i64 else torch.float64, f"xs[{g0 + i}]", n)
+            _dev(v, torch.uint8, f"xs_valid[{g0 + i}]", n)
+            vt = torch.int64 if i64 else torch.float64
+            is_i64.append(int(i64))
+            group.append(dict(mean=torch.empty(n, dtype=torch.float64, device=dev),
+                              count=torch.empty(n, dtype=torch.int64, device=dev),
+                              min=torch.empty(n, dtype=vt, device=dev), max=torch.empty(n, dtype=vt, device=dev),
+                              sum=torch.empty(n, dtype=vt, device=dev),
+                              stddev=torch.empty(n, dtype=torch.float64, device=dev),
+                              zscore=torch.empty(n, dtype=torch.float64, device=dev),
+                              valid=torch.empty(n, dtype=torch.uint8, device=dev)))
+        a = _lib.RangeStatsColsArgs()
+        a.n, a.key, a.n_keys, a.ts, a.ts_is_seconds = n, _p(key), int(n_keys), _p(ts), int(bool(ts_is_seconds))
+        a.range_back_secs, a.n_cols, a.out_perm = int(range_back_secs), k, _p(perm)
+        keep = [ptr_array([x.data_ptr() for x in gx]), ptr_array([_p(v) for v in gv]), (C.c_int32 * k)(*is_i64)]
+        a.x, a.x_valid, a.x_is_i64 = keep
+        for name, field in (("mean", "out_mean"), ("count", "out_count"), ("min", "out_min"), ("max", "out_max"),
+                            ("sum", "out_sum"), ("stddev", "out_stddev"), ("zscore", "out_zscore"),
+                            ("valid", "out_valid")):
+            arr = ptr_array([g[name].data_ptr() for g in group])
+            keep.append(arr)
+            setattr(a, field, arr)
+        if n:
+            _run_with_wide_fallback(lib().tmp_range_stats_cols, lib().tmp_range_stats_cols_workspace_bytes,
+                                    lib().tmp_range_stats_cols_wide_workspace_bytes, a, n, dev, "tmp_range_stats_cols")
+        outs.extend(group)
+    return perm, outs
 
 
 def ema_weights(window, exp_factor):

@@ -259,20 +259,27 @@ class TSDF:
             colsToSummarize = [c for c in self.df.columns
                                if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
         key, ts, secs, n_keys, _, _ = self._order_inputs(False)
-        # order the frame once; every per-column call then sees ordered input and skips its sort
-        perm = ops.sort_order(key, ts, n_keys, floor_seconds=not secs) if len(self.df) else None
-        if perm is not None:
-            order = perm.cpu().numpy()
-            key = ops.gather(key, perm, want_valid=False)[0] if key is not None else None
-            ts = ops.gather(ts, perm, want_valid=False)[0]
-        else:
-            order = np.arange(0)
-        df = self.df.iloc[order].reset_index(drop=True)
-        derived = {}
+        # one device call: the rows are ordered once, every metric column travels with them, and the
+        # frames' statistics are written column by column from that order
+        xs, xv, kinds = [], [], []
         for metric in colsToSummarize:
+            x, x_valid, kind = col.numeric_to_device(self.df[metric])
+            xs.append(x)
+            xv.append(x_valid)
+            kinds.append(kind)
+        if xs and len(self.df):
+            perm, outs = ops.range_stats_cols(key, ts, xs, xv, n_keys, rangeBackWindowSecs, ts_is_seconds=secs)
+        elif len(self.df):
+            perm, outs = ops.sort_order(key, ts, n_keys, floor_seconds=not secs), []
+        else:
+            perm = torch.empty(0, dtype=torch.int32)
+            outs = [{k: torch.empty(0, dtype=torch.int64 if (k == "count" or (kind == "i64" and k in ("min", "max", "sum")))
+                                    else torch.uint8 if k == "valid" else torch.float64)
+                     for k in ("mean", "count", "min", "max", "sum", "stddev", "zscore", "valid")} for kind in kinds]
+        df = self.df.iloc[perm.cpu().numpy()].reset_index(drop=True)
+        derived = {}
+        for metric, kind, out in zip(colsToSummarize, kinds, outs):
             s = df[metric]
-            x, x_valid, kind = col.numeric_to_device(s)
-            out = ops.range_stats(key, ts, x, x_valid, n_keys, rangeBackWindowSecs, ts_is_seconds=secs)
             valid = out["valid"].cpu().numpy()
             ok, sd_ok, z_ok = (valid & 1) != 0, (valid & 2) != 0, (valid & 4) != 0
             mean = np.where(ok, out["mean"].cpu().numpy(), np.nan)

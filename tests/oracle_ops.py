@@ -94,6 +94,14 @@ def range_stats(key, ts, x, x_valid, n_keys, range_back_secs, ts_is_seconds=Fals
     return out
 
 
+def range_stats_cols(key, ts, xs, xs_valid, n_keys, range_back_secs, ts_is_seconds=False):
+    outs = [range_stats(key, ts, x, v, n_keys, range_back_secs, ts_is_seconds) for x, v in zip(xs, xs_valid)]
+    perm = outs[0].pop("perm")
+    for o in outs[1:]:
+        assert torch.equal(o.pop("perm"), perm)
+    return perm, outs
+
+
 def ema(key, ts, x, x_valid, n_keys, window=30, exp_factor=0.2, ts_is_seconds=False, seq=None, seq_valid=None):
     perm, out = oracle.ema(_np(key), _np(ts), _np(x), _np(x_valid), window, exp_factor, ts_is_seconds=ts_is_seconds,
                            seq=_np(seq), seq_valid=_np(seq_valid))

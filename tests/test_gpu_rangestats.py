@@ -367,3 +367,48 @@ def test_range_stats_long_frames_after_a_long_run_of_nulls(orc, ops):
     # the oracle's sequential recurrence (Spark's own) adds values of 1e6 to a running mean: with a
     # spread of 1e-2 it keeps about seven digits of the standard deviation
     np.testing.assert_allclose(g["stddev"], ref["stddev"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("order", ["random", "time", "sorted"])
+@pytest.mark.parametrize("n_cols", [1, 3, 6])
+def test_range_stats_several_columns_in_one_call(orc, ops, order, n_cols):
+    """tmp_range_stats_cols: one ordering, every column travelling with the rows; column by column
+    the same results as the single-column call (bit for bit) and the oracle's.  Mixed double and
+    int64 columns, with and without NULLs; six columns go in two groups."""
+    rng = np.random.default_rng(50 + n_cols)
+    n, nk = 120_000, 9
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + (rng.exponential(0.2, n).cumsum() * 1e6).astype(np.int64)
+    if order == "random":
+        p = rng.permutation(n); key, ts = key[p], ts[p]
+    elif order == "sorted":
+        p = np.lexsort((ts, key)); key, ts = key[p], ts[p]
+    xs, xv = [], []
+    for c in range(n_cols):
+        if c % 3 == 1:
+            xs.append(rng.integers(1, 2000, n))   # positive: a mean of exactly 0 has no relative tolerance
+        else:
+            xs.append(100.0 * (c + 1) + rng.normal(0, 1, n).cumsum() * 0.01)
+        xv.append(None if c % 2 == 0 else (rng.random(n) >= 0.1 * c).astype(np.uint8))
+    perm, outs = ops.range_stats_cols(_dev(key), _dev(ts), [_dev(x) for x in xs], [_dev(v) for v in xv], nk, 30)
+    assert len(outs) == n_cols
+    for c in range(n_cols):
+        g, ref = _compare(orc, ops, key, ts, xs[c], xv[c], nk, 30)   # single-column call vs oracle
+        assert np.array_equal(perm.cpu().numpy(), g["perm"])
+        for name in ("mean", "count", "min", "max", "sum", "stddev", "zscore", "valid"):
+            assert np.array_equal(outs[c][name].cpu().numpy(), g[name], equal_nan=True), (c, name)
+
+
+def test_range_stats_several_columns_long_frames(orc, ops):
+    """Frames longer than the on-chip region with several columns: the wide path completes each."""
+    rng = np.random.default_rng(77)
+    n, nk = 60_000, 2
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + (rng.exponential(0.01, n).cumsum() * 1e6).astype(np.int64)   # ~100 rows per second
+    xs = [50.0 + rng.normal(0, 1, n), rng.integers(0, 50, n)]
+    xv = [(rng.random(n) >= 0.2).astype(np.uint8), None]
+    perm, outs = ops.range_stats_cols(_dev(key), _dev(ts), [_dev(x) for x in xs], [_dev(v) for v in xv], nk, 120)
+    for c in range(2):
+        g, ref = _compare(orc, ops, key, ts, xs[c], xv[c], nk, 120)
+        for name in ("mean", "count", "min", "max", "sum", "stddev", "zscore", "valid"):
+            assert np.array_equal(outs[c][name].cpu().numpy(), g[name], equal_nan=True), (c, name)

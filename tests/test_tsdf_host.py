@@ -13,7 +13,7 @@ def host_tsdf(monkeypatch, orc):
     import tempo_amd
     from tempo_amd import columns, ops
     monkeypatch.setattr(columns, "device", lambda: torch.device("cpu"))
-    for name in ("sort_order", "asof_join", "asof_join_table", "gather", "range_stats", "ema", "lookback", "resample", "grouped_stats", "interpolate",
+    for name in ("sort_order", "asof_join", "asof_join_table", "gather", "range_stats", "range_stats_cols", "ema", "lookback", "resample", "grouped_stats", "interpolate",
                  "write_layout"):
         monkeypatch.setattr(ops, name, getattr(oracle_ops, name))
     return tempo_amd.TSDF

@@ -26,7 +26,7 @@ import oracle_ops  # noqa: E402
 import tsdf_golden_cases as cases  # noqa: E402
 from tempo_amd import TSDF, columns, ops  # noqa: E402
 
-SWAPPED = ("sort_order", "asof_join", "asof_join_table", "gather", "range_stats", "ema", "lookback", "resample",
+SWAPPED = ("sort_order", "asof_join", "asof_join_table", "gather", "range_stats", "range_stats_cols", "ema", "lookback", "resample",
            "grouped_stats", "interpolate", "write_layout")
 
 
