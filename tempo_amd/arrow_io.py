@@ -142,74 +142,110 @@ def _stamps(us, typ):
     return pa.array(us, type=pa.int64()).cast(pa.timestamp("us", tz=typ.tz)).cast(typ)
 
 
+def spark_dtype(t):
+    """The Spark SQL type name of an Arrow type, as the reference's dtype checks would see it
+    (python/tempo/tsdf.py:697, python/tempo/resample.py:111)."""
+    if pa.types.is_dictionary(t):
+        t = t.value_type
+    if pa.types.is_boolean(t):
+        return "boolean"
+    if pa.types.is_timestamp(t):
+        return "timestamp"
+    if pa.types.is_integer(t):
+        return {8: "tinyint", 16: "smallint", 32: "int", 64: "bigint"}[t.bit_width]
+    if pa.types.is_floating(t):
+        return "float" if t.bit_width <= 32 else "double"
+    return "string"
+
+
 def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="right", skip_nulls=True,
-              ts_partition_val=None, fraction=0.5):
+              ts_partition_val=None, fraction=0.5, left_prefix=None, right_ts_col=None, with_info=False):
     """AS-OF join of two Arrow tables.  Returns the joined table ordered by (partition, ts):
-    partition columns, the left columns, then `<right_prefix>_<name>` for every right column."""
+    partition columns, the left columns (`<left_prefix>_<name>` when a left prefix is given), then
+    `<right_prefix>_<name>` for every right column ('' as a prefix keeps the name).
+
+    Only keys, timestamps and the right table's columns travel to the device; the left table's
+    rows follow by the row permutation the join returns -- or, when the left table arrives in
+    (partition, ts) order already, stay where they are: its columns are then the result's, untouched.
+    with_info: also return dict(missing=flags per rule, mask_of={right column: its NULL-mask slot},
+    in_place=bool)."""
     partition_cols = list(partition_cols)
-    (key_l, key_r), n_keys, decode_keys = encode_keys_dev([left, right], partition_cols)
+    right_ts_col = ts_col if right_ts_col is None else right_ts_col
+    (key_l, key_r), n_keys, _ = encode_keys_dev([left, right], partition_cols)
     ts_l, ts_type = timestamps_dev(left[ts_col])
-    ts_r, ts_type_r = timestamps_dev(right[ts_col])
+    ts_r, ts_type_r = timestamps_dev(right[right_ts_col])
     if ts_type != ts_type_r:
         raise ValueError("left and right dataframe timestamp index columns should have same type")
-    left_cols = [c for c in left.column_names if c not in partition_cols and c != ts_col]
+    left_cols = [c for c in left.column_names if c not in partition_cols]
     right_cols = [c for c in right.column_names if c not in partition_cols]
-    lenc = [payload_to_device(left[c]) for c in left_cols]
-    renc = [payload_to_device(right[c]) for c in right_cols]
-    j = ops.asof_join_table(key_l, ts_l, key_r, ts_r, n_keys,
-                            [t for t, _, _ in lenc], [t for t, _, _ in renc], [v for _, v, _ in renc],
-                            skip_nulls=skip_nulls, ts_partition_val=ts_partition_val, fraction=fraction)
-    names, arrays = [], []
-    if partition_cols:
-        for c, a in zip(partition_cols, decode_keys(j["key"].cpu().numpy())):
-            names.append(c)
-            arrays.append(a)
-    names.append(ts_col)
-    arrays.append(_stamps(j["ts"].cpu().numpy(), ts_type))
-    perm = j["perm"]
-    for i, c in enumerate(left_cols):
-        values, valid, dec = lenc[i]
-        if valid is None:
-            ok = np.ones(left.num_rows, bool)
-        else:  # the NULL mask of a left column follows its rows through the permutation
-            ok = ops.gather(valid, perm, want_valid=False)[0].cpu().numpy().astype(bool)
-        names.append(c)
-        arrays.append(dec(j["left"][i].cpu().numpy(), ok))
+    lname = {c: (c if left_prefix in (None, "") else f"{left_prefix}_{c}") for c in left_cols}
+    rname = {c: (c if right_prefix == "" else f"{right_prefix}_{c}") for c in right_cols}
+    clash = set(lname.values()) & set(rname.values())
+    if clash:
+        raise ValueError(f"duplicate column names after prefixing: {sorted(clash)}")
+    renc = []
+    for c in right_cols:
+        if c == right_ts_col:  # the join's own time column: already on the device
+            renc.append((ts_r, None, (lambda v, ok, t=ts_type_r: pa.array(v, type=pa.int64(), mask=~ok)
+                                      .cast(pa.timestamp("us", tz=t.tz)).cast(t))))
+        else:
+            renc.append(payload_to_device(right[c]))
+    j = ops.asof_join_table(key_l, ts_l, key_r, ts_r, n_keys, [], [t for t, _, _ in renc], [v for _, v, _ in renc],
+                            skip_nulls=skip_nulls, ts_partition_val=ts_partition_val, fraction=fraction,
+                            left_by_reference=True)
+    if j["in_place"]:
+        ordered_left = left
+    else:
+        ordered_left = left.take(pa.array(j["perm"].cpu().numpy()))
+    names = list(partition_cols) + [lname[c] for c in left_cols]
+    arrays = [ordered_left[c] for c in partition_cols] + [ordered_left[c] for c in left_cols]
     for i, c in enumerate(right_cols):
         vals, ok = j["right"][i]
-        names.append(f"{right_prefix}_{c}" if right_prefix != "" else c)
+        names.append(rname[c])
         arrays.append(renc[i][2](vals.cpu().numpy(), ok.cpu().numpy().astype(bool)))
-    return pa.table(arrays, names=names)
+    out = pa.table(arrays, names=names)
+    if not with_info:
+        return out
+    mask_of = {c: j["mask_of"][i] for i, c in enumerate(right_cols) if j["mask_of"][i] >= 0}
+    return out, dict(missing=j["missing"].cpu().numpy(), mask_of=mask_of, in_place=j["in_place"], names=rname)
 
 
 def range_stats(table, ts_col="event_ts", partition_cols=(), cols=(), range_back_secs=1000):
     """withRangeStats on an Arrow table: the input rows in (partition, ts) order plus
-    mean_/count_/min_/max_/sum_/stddev_/zscore_<col> for every column in `cols`."""
+    mean_/count_/min_/max_/sum_/stddev_/zscore_<col> for every column in `cols` -- one device call
+    for all of them (the rows are ordered once)."""
     partition_cols = list(partition_cols)
     (key_d,), n_keys, _ = encode_keys_dev([table], partition_cols)
     ts_d, _ = timestamps_dev(table[ts_col])
-    out, perm = None, None
-    extra = {}
+    xs, xv, types = [], [], []
     for c in cols:
         arr = _combined(table[c])
         if not (pa.types.is_floating(arr.type) or pa.types.is_integer(arr.type)):
             raise TypeError(f"column {c} of type {arr.type} is not numeric")
         x, valid, _ = payload_to_device(arr)
-        r = ops.range_stats(key_d, ts_d, x, valid, n_keys, range_back_secs)
+        xs.append(x)
+        xv.append(valid)
+        types.append(arr.type)
+    extra = {}
+    if xs and table.num_rows:
+        perm, outs = ops.range_stats_cols(key_d, ts_d, xs, xv, n_keys, range_back_secs)
+        perm = perm.cpu().numpy()
+    else:
+        perm = ops.sort_order(key_d, ts_d, n_keys, floor_seconds=True).cpu().numpy() if table.num_rows else np.arange(0)
+        outs = []
+    for c, typ, r in zip(cols, types, outs):
         flags = r["valid"].cpu().numpy()
         ok, sd_ok, z_ok = (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0
-        perm = r["perm"].cpu().numpy() if perm is None else perm
-        as_in = pa.float64() if pa.types.is_floating(arr.type) else pa.int64()
+        as_in = pa.float64() if pa.types.is_floating(typ) else pa.int64()
         extra["mean_" + c] = pa.array(r["mean"].cpu().numpy(), mask=~ok)
         extra["count_" + c] = pa.array(r["count"].cpu().numpy())
-        extra["min_" + c] = pa.array(r["min"].cpu().numpy(), type=as_in, mask=~ok).cast(arr.type)
-        extra["max_" + c] = pa.array(r["max"].cpu().numpy(), type=as_in, mask=~ok).cast(arr.type)
+        extra["min_" + c] = pa.array(r["min"].cpu().numpy(), type=as_in, mask=~ok).cast(typ)
+        extra["max_" + c] = pa.array(r["max"].cpu().numpy(), type=as_in, mask=~ok).cast(typ)
         extra["sum_" + c] = pa.array(r["sum"].cpu().numpy(), type=as_in, mask=~ok)
         extra["stddev_" + c] = pa.array(r["stddev"].cpu().numpy(), mask=~sd_ok)
         extra["zscore_" + c] = pa.array(r["zscore"].cpu().numpy(), mask=~z_ok)
-    if perm is None:
-        perm = ops.sort_order(key_d, ts_d, n_keys, floor_seconds=True).cpu().numpy() if table.num_rows else np.arange(0)
-    out = table.take(pa.array(perm.astype(np.int64)))
+    identity = len(perm) > 0 and perm[0] == 0 and perm[-1] == len(perm) - 1 and bool((np.diff(perm) == 1).all())
+    out = table if identity else table.take(pa.array(perm.astype(np.int64)))
     zs = [k for k in extra if k.startswith("zscore_")]
     for k in [k for k in extra if not k.startswith("zscore_")] + zs:  # zscore columns last (tsdf.py:718-719)
         out = out.append_column(k, extra[k])

@@ -22,13 +22,19 @@ def to_pandas(df):
     """Accept pandas DataFrames and pyarrow Tables."""
     if isinstance(df, pd.DataFrame):
         return df
-    try:
-        import pyarrow as pa
-        if isinstance(df, pa.Table):
-            return df.to_pandas()
-    except ImportError:  # pragma: no cover
-        pass
-    raise TypeError(f"df must be a pandas DataFrame or a pyarrow Table, got {type(df)}")
+    return to_arrow(df).to_pandas()
+
+
+def to_arrow(df):
+    """A pyarrow Table from a pyarrow Table / RecordBatch or a Spark DataFrame (collected through
+    Arrow); anything else is refused as the TSDF constructor's `df`."""
+    import pyarrow as pa
+    if isinstance(df, pa.Table):
+        return df
+    if isinstance(df, pa.RecordBatch) or type(df).__module__.startswith("pyspark"):
+        from . import spark_glue
+        return spark_glue.to_arrow(df)
+    raise TypeError(f"df must be a pandas DataFrame, a pyarrow Table or a Spark DataFrame, got {type(df)}")
 
 
 def to_dev(a):
@@ -175,7 +181,7 @@ def ordered_codes(series):
     struct comparisons on the device.  Returns (codes tensor, validity or None, uniques)."""
     mask = series.isna().to_numpy()
     uniq = np.array(sorted(series[~mask].unique()), dtype=object)
-    lookup = {v: i for i, v in enumerate(uniq)}
-    codes = np.fromiter((0 if m else lookup[v] for v, m in zip(series.to_numpy(dtype=object), mask)),
-                        dtype=np.int64, count=len(series))
+    # codes by one vectorised lookup (a categorical with the sorted dictionary), NULL -> code 0
+    codes = pd.Categorical(series, categories=uniq).codes.astype(np.int64)
+    codes[codes < 0] = 0
     return to_dev(codes), (to_dev((~mask).astype(np.uint8)) if mask.any() else None), uniq

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm)
       jpre[mm] = (same && mm < n_masks) ? lastnn[(size_t)mm * n_right + jr] : -1;
-    if (sorted_output) {
+    if (sorted_output && out_perm) {
       out_perm[i] = (int32_t)src_row;
       if (out_key) out_key[i] = (int32_t)key_l;
       if (out_ts) out_ts[i] = lay.prim_of(wl);
@@ -654,8 +654,13 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   OrderSpec lay_spec = rs;  // the key field exists if either side carries keys (one may be empty)
   if (!lay_spec.key) lay_spec.key = ls.key;
   TMP_TRY(order_make_layout(lay_spec, both, a->n_masks, &lay));
+  // a left table that is in order already can be used by reference (the right one is not, or the
+  // one-sweep join above would have taken the call): row p of the result is left row p, and the
+  // caller's own key / time / payload columns stand for out_perm, out_key, out_ts, out_left_cols
+  const bool left_ref = a->sorted_output && a->left_in_place != nullptr && !rl.unsorted;
+  if (left_ref) *a->left_in_place = 1;
   // payload columns of the fused join
-  const int nlc = a->sorted_output ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
+  const int nlc = (a->sorted_output && !left_ref) ? a->n_left_cols : 0, nrc = a->sorted_output ? a->n_right_cols : 0;
   JoinCols jc;
   memset(&jc, 0, sizeof(jc));
   jc.n_left = nlc;
@@ -757,11 +762,13 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     if (jc.n <= 4 && a->n_masks <= 4)
       hipLaunchKernelGGL((asof_merge_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
                          ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                         a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
+                         a->out_missing, a->sorted_output, left_ref ? nullptr : a->out_perm, left_ref ? nullptr : a->out_key,
+                         left_ref ? nullptr : a->out_ts, jc, p.block_bounds, cmask);
     else
       hipLaunchKernelGGL((asof_merge_kernel<0, 0>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
                          ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
-                         a->out_missing, a->sorted_output, a->out_perm, a->out_key, a->out_ts, jc, p.block_bounds, cmask);
+                         a->out_missing, a->sorted_output, left_ref ? nullptr : a->out_perm, left_ref ? nullptr : a->out_key,
+                         left_ref ? nullptr : a->out_ts, jc, p.block_bounds, cmask);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;

@@ -6,7 +6,7 @@ Spark hands a Python worker its partition as an iterator of `pyarrow.RecordBatch
 must be whole inside one partition, so the job repartitions by the partition columns first:
 
     fn = spark_glue.range_stats_in_arrow("event_ts", ["symbol"], ["price"], 600)
-    out = df.repartition("symbol").mapInArrow(fn, schema=spark_glue.range_stats_schema(df.schema, ["price"]))
+    out = df.repartition("symbol").mapInArrow(fn, schema=<df.schema + spark_glue.range_stats_fields(arrow schema of df, ["price"])>)
 
     fn = spark_glue.asof_join_in_arrow("event_ts", ["symbol"], right_prefix="right")
     out = left.groupBy("symbol").cogroup(right.groupBy("symbol")).applyInArrow(fn, schema=...)

@@ -2,9 +2,13 @@
 
 Same class, method names, arguments, column naming and error behaviour as
 python/tempo/tsdf.py for the hot path (asofJoin incl. the tsPartitionVal/fraction skew mode,
-withRangeStats, EMA, withLookbackFeatures, resample); `df` is a pandas DataFrame (or a pyarrow
-Table) instead of a Spark DataFrame.  Every O(rows) computation runs in libtempo_hip.so on the
-GPU; this module only re-encodes columns, names outputs and raises the reference's errors.
+withRangeStats, EMA, withLookbackFeatures, resample); `df` is a pandas DataFrame, a pyarrow Table
+or a Spark DataFrame (taken over as Arrow).  Every O(rows) computation runs in libtempo_hip.so
+on the GPU; this module only re-encodes columns, names outputs and raises the reference's errors.
+
+A TSDF built on Arrow data stays on Arrow: asofJoin and withRangeStats move the Arrow buffers to
+the device as they are, assemble their result as an Arrow table and hand back a TSDF that holds
+it; `.df` turns it into pandas only when somebody asks.
 """
 import logging
 
@@ -26,21 +30,49 @@ _SUMMARIZABLE = ['int', 'bigint', 'float', 'double']  # python/tempo/tsdf.py:697
 class TSDF:
 
     def __init__(self, df, ts_col="event_ts", partition_cols=None, sequence_col=None):
-        """python/tempo/tsdf.py:24-36."""
-        df = col.to_pandas(df)
-        self.ts_col = self.__validated_column(df, ts_col)
-        self.partitionCols = [] if partition_cols is None else self.__validated_columns(df, partition_cols)
-        self.df = df
+        """python/tempo/tsdf.py:24-36.  df: pandas DataFrame, pyarrow Table / RecordBatch, or a Spark
+        DataFrame (collected through Arrow)."""
+        self._pandas, self._table = None, None
+        if isinstance(df, pd.DataFrame):
+            self._pandas = df
+            names = list(df.columns)
+        else:
+            self._table = col.to_arrow(df)
+            names = list(self._table.column_names)
+        self.ts_col = self.__validated_column(names, ts_col)
+        self.partitionCols = [] if partition_cols is None else self.__validated_columns(names, partition_cols)
         self.sequence_col = '' if sequence_col is None else sequence_col
+
+    @property
+    def df(self):
+        """The table as a pandas DataFrame (built from the Arrow table on first use)."""
+        if self._pandas is None:
+            self._pandas = self._table.to_pandas()
+        return self._pandas
+
+    @df.setter
+    def df(self, value):
+        self._pandas, self._table = value, None
+
+    @property
+    def table(self):
+        """The table as a pyarrow Table (built from the pandas frame on first use)."""
+        if self._table is None:
+            import pyarrow as pa
+            self._table = pa.Table.from_pandas(self._pandas, preserve_index=False)
+        return self._table
+
+    def _on_arrow(self):
+        return self._table is not None
 
     ##
     ## Helper functions
     ##
 
-    def __validated_column(self, df, colname):  # tsdf.py:45-50
+    def __validated_column(self, names, colname):  # tsdf.py:45-50
         if type(colname) != str:
             raise TypeError(f"Column names must be of type str; found {type(colname)} instead!")
-        if colname.lower() not in [c.lower() for c in df.columns]:
+        if colname.lower() not in [c.lower() for c in names]:
             raise ValueError(f"Column {colname} not found in Dataframe")
         return colname
 
@@ -60,9 +92,15 @@ class TSDF:
             if left_col != right_col:
                 raise ValueError("left and right dataframe partition columns should have same name in same order")
 
+    def _spark_dtype(self, name):
+        if self._on_arrow():
+            from . import arrow_io
+            return arrow_io.spark_dtype(self._table.schema.field(name).type)
+        return col.spark_dtype(self.df[name])
+
     def __validateTsColMatch(self, right_tsdf):  # tsdf.py:71-75
-        left_ts_datatype = col.spark_dtype(self.df[self.ts_col])
-        right_ts_datatype = col.spark_dtype(right_tsdf.df[right_tsdf.ts_col])
+        left_ts_datatype = self._spark_dtype(self.ts_col)
+        right_ts_datatype = right_tsdf._spark_dtype(right_tsdf.ts_col)
         if left_ts_datatype != right_ts_datatype:
             raise ValueError("left and right dataframe timestamp index columns should have same type")
 
@@ -92,6 +130,11 @@ class TSDF:
             raise ValueError("Disabling null skipping with a partition value is not supported yet.")
         if tsPartitionVal is not None and not isinstance(tsPartitionVal, (int, float)):
             raise TypeError("tsPartitionVal must be an int or a float")
+
+        if (self._on_arrow() and right_tsdf._on_arrow() and not right_tsdf.sequence_col
+                and self._spark_dtype(self.ts_col) == "timestamp"):
+            return self.__asofJoinArrow(right_tsdf, left_prefix, right_prefix, tsPartitionVal, fraction, skipNulls,
+                                        suppress_null_warning)
 
         left_df, right_df = self.df, right_tsdf.df
         part = self.partitionCols
@@ -179,6 +222,25 @@ class TSDF:
                                    "in the data frame, this warning can be ignored.")
         return TSDF(joined, lname[self.ts_col], part)
 
+    def __asofJoinArrow(self, right_tsdf, left_prefix, right_prefix, tsPartitionVal, fraction, skipNulls,
+                        suppress_null_warning):
+        """asofJoin of two Arrow-backed tables (timestamp time index, no sequence column): Arrow buffers
+        to the device, the joined table assembled as Arrow; same names and warnings as the pandas way."""
+        from . import arrow_io
+        joined, info = arrow_io.asof_join(self._table, right_tsdf._table, self.ts_col, self.partitionCols,
+                                          right_prefix=right_prefix, skip_nulls=bool(skipNulls),
+                                          ts_partition_val=tsPartitionVal, fraction=fraction, left_prefix=left_prefix,
+                                          right_ts_col=right_tsdf.ts_col, with_info=True)
+        if tsPartitionVal is not None and (not suppress_null_warning or logger.isEnabledFor(logging.WARNING)):
+            miss = info["missing"]
+            for c, name in info["names"].items():  # tsdf.py:150-158
+                if miss[1 + info["mask_of"][c]] if c in info["mask_of"] else miss[0]:
+                    logger.warning("Column " + name + " had no values within the lookback window. Consider "
+                                   "using a larger window to avoid missing values. If this is the first record "
+                                   "in the data frame, this warning can be ignored.")
+        ts_name = self.ts_col if left_prefix in (None, '') else left_prefix + '_' + self.ts_col
+        return TSDF(joined, ts_name, self.partitionCols)
+
     ##
     ## window ordering shared by withRangeStats / EMA / withLookbackFeatures (tsdf.py:563-580)
     ##
@@ -236,12 +298,14 @@ class TSDF:
         if fv is not None:
             feat = np.where(fv.cpu().numpy().astype(bool), feat, np.nan)
         df = self.df.iloc[rows].reset_index(drop=True)
+        # one object cell per row without a Python loop: a list of the leading axis' views
+        cells = np.empty(len(rows), dtype=object)
         if exactSize:
-            cells = [feat[i] for i in range(len(rows))]
+            cells[:] = list(feat)
         else:
             ln = lens.cpu().numpy()
-            cells = [feat[i, :ln[i]] for i in range(len(rows))]
-        df[featureColName] = pd.Series(cells, dtype=object)
+            cells[:] = [f[:k] for f, k in zip(feat, ln)]
+        df[featureColName] = pd.Series(cells, dtype=object, index=df.index)
         if exactSize:
             return df
         return TSDF(df, self.ts_col, self.partitionCols)
@@ -256,8 +320,14 @@ class TSDF:
                              "exactly one ordering expression")
         if not colsToSummarize:
             prohibited_cols = [self.ts_col.lower()] + [pc.lower() for pc in self.partitionCols]
-            colsToSummarize = [c for c in self.df.columns
-                               if col.spark_dtype(self.df[c]) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+            names = self._table.column_names if self._on_arrow() else self.df.columns
+            colsToSummarize = [c for c in names
+                               if self._spark_dtype(c) in _SUMMARIZABLE and c.lower() not in prohibited_cols]
+        if self._on_arrow() and self._spark_dtype(self.ts_col) == "timestamp":
+            from . import arrow_io
+            out = arrow_io.range_stats(self._table, self.ts_col, self.partitionCols, list(colsToSummarize),
+                                       rangeBackWindowSecs)
+            return TSDF(out, self.ts_col, self.partitionCols)
         key, ts, secs, n_keys, _, _ = self._order_inputs(False)
         # one device call: the rows are ordered once, every metric column travels with them, and the
         # frames' statistics are written column by column from that order

@@ -27,3 +27,60 @@ def test_skew_warnings_are_logged(caplog):
     text = " ".join(r.getMessage() for r in caplog.records)
     assert "skew version of the AS OF join" in text
     assert "Column right_y had no values within the lookback window" in text
+
+
+def _arrow_backed():
+    """TSDF that turns every pandas frame it is given into a pyarrow Table first: the golden cases
+    then run through the Arrow-native paths of asofJoin and withRangeStats."""
+    import pandas as pd
+    import pyarrow as pa
+    from tempo_amd import TSDF
+
+    class Meta(type):   # the cases ask isinstance(result, TSDF) of results the base class built
+        def __instancecheck__(cls, obj):
+            return isinstance(obj, TSDF)
+
+    class ArrowTSDF(TSDF, metaclass=Meta):
+        def __init__(self, df, *args, **kwargs):
+            if isinstance(df, pd.DataFrame):
+                df = pa.Table.from_pandas(df, preserve_index=False)
+            super().__init__(df, *args, **kwargs)
+    return ArrowTSDF
+
+
+@pytest.mark.parametrize("case", cases.ALL_CASES, ids=lambda c: c.__name__)
+def test_reference_case_with_arrow_tables(case):
+    case(_arrow_backed())
+
+
+def test_arrow_backed_join_stays_on_arrow():
+    """An Arrow-backed asofJoin / withRangeStats hands back an Arrow-backed TSDF (no pandas frame is
+    built unless asked for), equal to the pandas-backed result; a left table in order is used by
+    reference (the joined table's left columns are the caller's own Arrow columns)."""
+    import numpy as np
+    import pandas as pd
+    import pyarrow as pa
+    from tempo_amd import TSDF
+    rng = np.random.default_rng(3)
+    n = 50_000
+    mk = lambda: pd.DataFrame({"symbol": rng.choice(["a", "b", "c", None], n), "event_ts": pd.to_datetime("2020-08-01") +
+                               pd.to_timedelta(rng.integers(0, 3_600_000, n), unit="ms"),
+                               "v": rng.normal(0, 1, n), "q": rng.integers(0, 9, n).astype(np.int32)})
+    left, right = mk(), mk()
+    right.loc[rng.random(n) < 0.2, "v"] = np.nan
+    al, ar = (pa.Table.from_pandas(t, preserve_index=False) for t in (left, right))
+    got = TSDF(al, partition_cols=["symbol"]).asofJoin(TSDF(ar, partition_cols=["symbol"]), left_prefix="l")
+    assert got._pandas is None and got.ts_col == "l_event_ts"
+    want = TSDF(left, partition_cols=["symbol"]).asofJoin(TSDF(right, partition_cols=["symbol"]), left_prefix="l")
+    cases.assert_frames_equal(got.df, want.df, decimals=9)
+    st = TSDF(al, partition_cols=["symbol"]).withRangeStats(colsToSummarize=["v", "q"], rangeBackWindowSecs=60)
+    assert st._pandas is None
+    cases.assert_frames_equal(st.df, TSDF(left, partition_cols=["symbol"]).withRangeStats(
+        colsToSummarize=["v", "q"], rangeBackWindowSecs=60).df, decimals=9)
+    # a left table already in (symbol, event_ts) order: its columns pass through untouched
+    o = left.sort_values(["symbol", "event_ts"], kind="stable", na_position="first").reset_index(drop=True)
+    ol = pa.Table.from_pandas(o, preserve_index=False)
+    j = TSDF(ol, partition_cols=["symbol"]).asofJoin(TSDF(ar, partition_cols=["symbol"]))
+    assert j.table["v"].chunks[0].buffers()[1].address == ol["v"].chunks[0].buffers()[1].address
+    cases.assert_frames_equal(j.df, TSDF(o, partition_cols=["symbol"]).asofJoin(TSDF(right, partition_cols=["symbol"])).df,
+                              decimals=9)

@@ -87,3 +87,29 @@ def test_table_path_stays_inside_the_warehouse(tmp_path):
             tio.table_path(root, bad)
     with pytest.raises(ValueError):
         tio.table_path(root, None)
+
+
+def test_constructor_takes_arrow_tables_and_spark_frames():
+    """python/tempo/tsdf.py:24-36 holds a Spark DataFrame; here a pyarrow Table is kept as it is (pandas
+    only on request) and anything from a pyspark module is taken over through its Arrow export."""
+    import pandas as pd
+    import pyarrow as pa
+    from tempo_amd import TSDF
+    frame = pd.DataFrame({"symbol": ["a", "b"], "event_ts": pd.to_datetime(["2020-01-01", "2020-01-02"]), "x": [1.0, 2.0]})
+    table = pa.Table.from_pandas(frame, preserve_index=False)
+    t = TSDF(table, partition_cols=["symbol"])
+    assert t._pandas is None and t.table is table and t.partitionCols == ["symbol"]
+    assert t.df.equals(frame) and t._pandas is not None
+    with pytest.raises(ValueError):
+        TSDF(table, ts_col="nope")
+    with pytest.raises(TypeError):
+        TSDF(table, ts_col=3)
+    with pytest.raises(TypeError):
+        TSDF([1, 2, 3])
+
+    class FakeSparkFrame:   # stands in for pyspark.sql.DataFrame: only its module name and toArrow() matter
+        def toArrow(self):
+            return table
+    FakeSparkFrame.__module__ = "pyspark.sql.dataframe"
+    s = TSDF(FakeSparkFrame(), partition_cols=["symbol"])
+    assert s.table is table and s.ts_col == "event_ts"
