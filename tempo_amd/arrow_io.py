@@ -119,27 +119,116 @@ def timestamps_us(arr):
 
 def payload_to_device(arr):
     """(8-byte device tensor, uint8 validity tensor or None, decode) for a payload column of the
-    fused join: integers, floats, timestamps and dictionary-encodable columns (strings)."""
+    fused join: integers, floats, timestamps and dictionary-encodable columns (strings).
+    decode(values, ok) takes host arrays -- int64 / float64 values and a bool (or None) mask of the
+    rows that are not NULL -- and returns the Arrow array of the column's own type."""
     t = arr.type
     if pa.types.is_floating(t) and t != pa.float16():
         vals, valid, _ = ops.arrow_import(arr, "f64")
-        dec = lambda v, ok: pa.array(v, type=pa.float64(), mask=~ok).cast(t)
+        dec = lambda v, ok: _masked(v, pa.float64(), ok).cast(t)
     elif pa.types.is_integer(t):
         vals, valid, _ = ops.arrow_import(arr, "i64")
-        dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
+        dec = lambda v, ok: _masked(v, pa.int64(), ok).cast(t)
     elif pa.types.is_timestamp(t):
         vals, valid, _ = ops.arrow_import(arr, "i64_raw")
-        dec = lambda v, ok: pa.array(v, type=pa.int64(), mask=~ok).cast(t)
+        dec = lambda v, ok: _masked(v, pa.int64(), ok).cast(t)
     else:
         enc = pc.dictionary_encode(_combined(arr))
         vals, valid, _ = ops.arrow_import(enc.indices, "i64")
         dictionary = enc.dictionary
-        dec = lambda v, ok: dictionary.take(pa.array(v, type=pa.int64(), mask=~ok))
+        dec = lambda v, ok: dictionary.take(_masked(v, pa.int64(), ok))
     return vals, valid, dec
 
 
-def _stamps(us, typ):
-    return pa.array(us, type=pa.int64()).cast(pa.timestamp("us", tz=typ.tz)).cast(typ)
+def _masked(values, typ, ok):
+    """Arrow array over a host numpy array without copying it; `ok`: None (no NULLs), a bool array,
+    or a (bit-packed validity bytes, null count) pair as to_host() returns it for a mask."""
+    values = np.ascontiguousarray(values)
+    n = len(values)
+    if ok is None:
+        return pa.Array.from_buffers(typ, n, [None, pa.py_buffer(values)], null_count=0)
+    if isinstance(ok, tuple):
+        bits, nulls = ok
+        return pa.Array.from_buffers(typ, n, [pa.py_buffer(bits), pa.py_buffer(values)], null_count=int(nulls))
+    return pa.array(values, type=typ, mask=~ok)
+
+
+def pack_validity(valid):
+    """Device uint8 mask (1 = not NULL) -> (bit-packed device bytes as Arrow lays a validity bitmap
+    out, least significant bit first; NULL count as a device scalar)."""
+    n = valid.numel()
+    pad = (-n) % 8
+    v = valid if pad == 0 else torch.cat([valid, valid.new_zeros(pad)])
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=valid.device)
+    bits = (v.view(-1, 8).to(torch.int32) * weights).sum(1).to(torch.uint8)
+    return bits, n - valid.sum()
+
+
+def to_host(tensors):
+    """Device tensors -> host numpy arrays through page-locked staging buffers, all copies in flight
+    together and one wait at the end (torch keeps freed page-locked blocks for the next call).  The
+    arrays own their memory: Arrow buffers built over them keep it alive."""
+    outs = []
+    for t in tensors:
+        if t is None:
+            outs.append(None)
+            continue
+        h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    torch.cuda.current_stream().synchronize()
+    return [None if h is None else h.numpy() for h in outs]
+
+
+def _device_permutable(t):
+    return (pa.types.is_integer(t) or (pa.types.is_floating(t) and t != pa.float16()) or pa.types.is_timestamp(t))
+
+
+def key_of(partition_cols, codes, decode):
+    """permute_table's `key` argument for a table with exactly one partition column."""
+    return (partition_cols[0], codes, decode) if len(partition_cols) == 1 and codes is not None else None
+
+
+def permute_table(table, perm, key=None):
+    """table.take(perm) with the fixed-width columns reordered on the device (one import, one gather,
+    one copy back per column) and only the others -- strings, nested types -- taken on the host.
+    perm: int32 device tensor.  key = (column name, int32 device codes, decode): that column is
+    rebuilt from its dictionary codes, reordered on the device, instead of being taken on the host."""
+    names, arrays, perm_host = [], [], None
+    pending = []  # (position, values tensor, validity tensor or None, type)
+    key_at = key_codes = None
+    for c in table.column_names:
+        arr = table[c]
+        names.append(c)
+        if key is not None and c == key[0] and table.num_rows:
+            key_at, key_codes = len(arrays), ops.gather(key[1], perm, want_valid=False)[0]
+            arrays.append(None)
+        elif _device_permutable(arr.type) and table.num_rows:
+            kind = "f64" if pa.types.is_floating(arr.type) else ("i64_raw" if pa.types.is_timestamp(arr.type) else "i64")
+            vals, valid, _ = ops.arrow_import(arr, kind)
+            moved = ops.gather(vals, perm, want_valid=False)[0]
+            mvalid = None if valid is None else ops.gather(valid, perm, want_valid=False)[0]
+            pending.append((len(arrays), moved, mvalid, arr.type))
+            arrays.append(None)
+        else:
+            if perm_host is None:
+                perm_host = pa.array(to_host([perm])[0])
+            arrays.append(arr.take(perm_host))
+    flat = [key_codes] if key_codes is not None else []
+    for _, moved, mvalid, _ in pending:
+        flat.append(moved)
+        if mvalid is not None:
+            bits, nulls = pack_validity(mvalid)
+            flat += [bits, nulls.reshape(1)]
+    host = iter(to_host(flat))
+    if key_codes is not None:
+        arrays[key_at] = key[2](next(host))[0]
+    for at, _, mvalid, typ in pending:
+        v = next(host)
+        ok = None if mvalid is None else (next(host), int(next(host)[0]))
+        wide = pa.float64() if pa.types.is_floating(typ) else pa.int64()
+        arrays[at] = _masked(v, wide, ok).cast(typ)
+    return names, arrays
 
 
 def spark_dtype(t):
@@ -171,7 +260,7 @@ def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="r
     in_place=bool)."""
     partition_cols = list(partition_cols)
     right_ts_col = ts_col if right_ts_col is None else right_ts_col
-    (key_l, key_r), n_keys, _ = encode_keys_dev([left, right], partition_cols)
+    (key_l, key_r), n_keys, decode_keys = encode_keys_dev([left, right], partition_cols)
     ts_l, ts_type = timestamps_dev(left[ts_col])
     ts_r, ts_type_r = timestamps_dev(right[right_ts_col])
     if ts_type != ts_type_r:
@@ -186,7 +275,7 @@ def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="r
     renc = []
     for c in right_cols:
         if c == right_ts_col:  # the join's own time column: already on the device
-            renc.append((ts_r, None, (lambda v, ok, t=ts_type_r: pa.array(v, type=pa.int64(), mask=~ok)
+            renc.append((ts_r, None, (lambda v, ok, t=ts_type_r: _masked(v, pa.int64(), ok)
                                       .cast(pa.timestamp("us", tz=t.tz)).cast(t))))
         else:
             renc.append(payload_to_device(right[c]))
@@ -194,15 +283,21 @@ def asof_join(left, right, ts_col="event_ts", partition_cols=(), right_prefix="r
                             skip_nulls=skip_nulls, ts_partition_val=ts_partition_val, fraction=fraction,
                             left_by_reference=True)
     if j["in_place"]:
-        ordered_left = left
+        lnames, larrays = list(left.column_names), [left[c] for c in left.column_names]
     else:
-        ordered_left = left.take(pa.array(j["perm"].cpu().numpy()))
+        lnames, larrays = permute_table(left, j["perm"], key_of(partition_cols, key_l, decode_keys))
+    by_name = dict(zip(lnames, larrays))
     names = list(partition_cols) + [lname[c] for c in left_cols]
-    arrays = [ordered_left[c] for c in partition_cols] + [ordered_left[c] for c in left_cols]
+    arrays = [by_name[c] for c in partition_cols] + [by_name[c] for c in left_cols]
+    flat = []
+    for vals, ok in j["right"]:
+        bits, nulls = pack_validity(ok)
+        flat += [vals, bits, nulls.reshape(1)]
+    host = iter(to_host(flat))
     for i, c in enumerate(right_cols):
-        vals, ok = j["right"][i]
+        v, bits, nulls = next(host), next(host), int(next(host)[0])
         names.append(rname[c])
-        arrays.append(renc[i][2](vals.cpu().numpy(), ok.cpu().numpy().astype(bool)))
+        arrays.append(renc[i][2](v, (bits, nulls)))
     out = pa.table(arrays, names=names)
     if not with_info:
         return out
@@ -215,7 +310,7 @@ def range_stats(table, ts_col="event_ts", partition_cols=(), cols=(), range_back
     mean_/count_/min_/max_/sum_/stddev_/zscore_<col> for every column in `cols` -- one device call
     for all of them (the rows are ordered once)."""
     partition_cols = list(partition_cols)
-    (key_d,), n_keys, _ = encode_keys_dev([table], partition_cols)
+    (key_d,), n_keys, decode_keys = encode_keys_dev([table], partition_cols)
     ts_d, _ = timestamps_dev(table[ts_col])
     xs, xv, types = [], [], []
     for c in cols:
@@ -229,23 +324,36 @@ def range_stats(table, ts_col="event_ts", partition_cols=(), cols=(), range_back
     extra = {}
     if xs and table.num_rows:
         perm, outs = ops.range_stats_cols(key_d, ts_d, xs, xv, n_keys, range_back_secs)
-        perm = perm.cpu().numpy()
     else:
-        perm = ops.sort_order(key_d, ts_d, n_keys, floor_seconds=True).cpu().numpy() if table.num_rows else np.arange(0)
+        perm = (ops.sort_order(key_d, ts_d, n_keys, floor_seconds=True) if table.num_rows
+                else torch.empty(0, dtype=torch.int32))
         outs = []
+    n = table.num_rows
+    flat = []
+    for r in outs:
+        flags = r["valid"]
+        for bit in (1, 2, 4):
+            bits, nulls = pack_validity((flags & bit) != 0)
+            flat += [bits, nulls.reshape(1)]
+        flat += [r[k] for k in ("mean", "count", "min", "max", "sum", "stddev", "zscore")]
+    identity = n == 0 or bool((perm == torch.arange(n, dtype=torch.int32, device=perm.device)).all())
+    host = iter(to_host(flat))
     for c, typ, r in zip(cols, types, outs):
-        flags = r["valid"].cpu().numpy()
-        ok, sd_ok, z_ok = (flags & 1) != 0, (flags & 2) != 0, (flags & 4) != 0
+        ok, sd_ok, z_ok = ((next(host), int(next(host)[0])) for _ in range(3))
+        mean, count, mn, mx, sm, sd, zs = (next(host) for _ in range(7))
         as_in = pa.float64() if pa.types.is_floating(typ) else pa.int64()
-        extra["mean_" + c] = pa.array(r["mean"].cpu().numpy(), mask=~ok)
-        extra["count_" + c] = pa.array(r["count"].cpu().numpy())
-        extra["min_" + c] = pa.array(r["min"].cpu().numpy(), type=as_in, mask=~ok).cast(typ)
-        extra["max_" + c] = pa.array(r["max"].cpu().numpy(), type=as_in, mask=~ok).cast(typ)
-        extra["sum_" + c] = pa.array(r["sum"].cpu().numpy(), type=as_in, mask=~ok)
-        extra["stddev_" + c] = pa.array(r["stddev"].cpu().numpy(), mask=~sd_ok)
-        extra["zscore_" + c] = pa.array(r["zscore"].cpu().numpy(), mask=~z_ok)
-    identity = len(perm) > 0 and perm[0] == 0 and perm[-1] == len(perm) - 1 and bool((np.diff(perm) == 1).all())
-    out = table if identity else table.take(pa.array(perm.astype(np.int64)))
+        extra["mean_" + c] = _masked(mean, pa.float64(), ok)
+        extra["count_" + c] = _masked(count, pa.int64(), None)
+        extra["min_" + c] = _masked(mn, as_in, ok).cast(typ)
+        extra["max_" + c] = _masked(mx, as_in, ok).cast(typ)
+        extra["sum_" + c] = _masked(sm, as_in, ok)
+        extra["stddev_" + c] = _masked(sd, pa.float64(), sd_ok)
+        extra["zscore_" + c] = _masked(zs, pa.float64(), z_ok)
+    if identity:
+        out = table
+    else:
+        names, arrays = permute_table(table, perm, key_of(partition_cols, key_d, decode_keys))
+        out = pa.table(arrays, names=names)
     zs = [k for k in extra if k.startswith("zscore_")]
     for k in [k for k in extra if not k.startswith("zscore_")] + zs:  # zscore columns last (tsdf.py:718-719)
         out = out.append_column(k, extra[k])

@@ -19,7 +19,7 @@ import pyarrow as pa
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tempo_amd import TSDF, columns, ops  # noqa: E402
+from tempo_amd import TSDF, arrow_io, columns, ops  # noqa: E402
 
 BASE = np.datetime64("2020-08-01T00:00:00", "us")
 PCIE_GBPS = 50.0  # what pinned copies reach on the box (profiles/r01_pcie_inclusive.json: 53 GB/s)
@@ -80,6 +80,7 @@ class Phases:
         for name in ("asof_join_table", "range_stats_cols", "range_stats", "sort_order"):
             self._wrap(ops, name, "device")
         self._wrap(torch.Tensor, "cpu", "d2h", lambda out, a: tens(out) if a[0].is_cuda else 0)
+        self._wrap(arrow_io, "to_host", "d2h", lambda out, a: sum(o.nbytes for o in out if o is not None))
         return self
 
     def __exit__(self, *exc):
