@@ -205,7 +205,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-        from tempo_amd.dist import all_reduce, balanced_owners, shuffle_by_key_start
+        from tempo_amd.dist import all_reduce, balanced_owners, plan_wire, shuffle_by_key_start
 
     verbose = os.environ.get("TEMPO_BENCH_VERBOSE") == "1"
 
@@ -241,12 +241,18 @@ def main():
                                        ts=[tq["ts_l"], tq["ts_r"]])
             own_ticks = balanced_owners(tk["key"], TICK_KEYS)
             log("owner plans ready (join keys sliced: %s)" % (own_join.slices is not None))
-            p_trades = shuffle_by_key_start(tq["key_l"], [tq["ts_l"], tq["trade_pr"]], owners=own_join,
-                                            ts=tq["ts_l"])
-            p_quotes = shuffle_by_key_start(
-                tq["key_r"], [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]],
-                owners=own_join, ts=tq["ts_r"], halo=True)
-            p_ticks = shuffle_by_key_start(tk["key"], [tk["ts"], tk["x"], tk["x_valid"]], owners=own_ticks)
+            # the columns travel narrowed: key + NULL flags in one or two bytes, timestamps as 5-byte
+            # offsets from the global minimum (dist.WirePlan)
+            c_trades = [tq["ts_l"], tq["trade_pr"]]
+            c_quotes = [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]]
+            c_ticks = [tk["ts"], tk["x"], tk["x_valid"]]
+            p_trades = shuffle_by_key_start(tq["key_l"], c_trades, owners=own_join, ts=tq["ts_l"],
+                                            wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS))
+            p_quotes = shuffle_by_key_start(tq["key_r"], c_quotes, owners=own_join, ts=tq["ts_r"], halo=True,
+                                            wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS))
+            p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
+                                           wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
+            exchange_bytes.append(p_trades.bytes_sent + p_quotes.bytes_sent + p_ticks.bytes_sent)
             log("exchanges issued")
             kl, (tl, pr), _, _ = p_trades.wait()
             kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
@@ -281,6 +287,7 @@ def main():
     # join orders its two sides on two streams at once, so the sum of its kernels' own durations
     # would count the overlapped time twice
     op_marks = []
+    exchange_bytes = []  # per step: bytes this rank handed to the exchange (all peers, itself included)
 
     for _ in range(args.warmup):
         step()
@@ -453,6 +460,9 @@ def main():
                              "with interleaved keys)" % (n_left, n_right, rows)),
                 "rows_per_gpu_per_op": rows,
                 "rccl_ranks": rccl_ranks,
+                "exchange_bytes_per_rank": (int(sum(exchange_bytes[-args.steps:]) / args.steps) if exchange_bytes else 0),
+                "multi_gpu_measured": ("this line" if rccl_ranks > 1 else
+                                       "no: one rank; 2/4/8-GPU timings need a multi-GPU node"),
                 "rows_held_per_rank": rows_per_rank,
                 "range_stats_shuffled_ms_per_step": None if shuffled_ms is None else round(shuffled_ms, 3),
                 "asof_sorted_input_ms_per_step": None if sorted_ms is None else round(sorted_ms, 3),

@@ -15,13 +15,19 @@ import torch.distributed as dist
 
 from . import ops
 
-# Largest single message handed to the collective, in bytes.  Columns of 10^9 rows are several
-# GB per peer; they go out as a sequence of all-to-alls over row ranges of at most this size.
-# Why: on this RCCL build a rank's send to itself delivers a message of 1 GiB intact but only
-# the first half of one between 2 GiB and 8 GB (the tail of the receive buffer is left untouched;
-# every entry point -- all_to_all_single with or without split sizes and the grouped send/recv
-# form -- behaves the same, so the loss is below torch; tools/a2a_probe.py reproduces it).
-# Half a GiB keeps every message a factor of two clear of the largest size seen to work.
+# Largest amount of data handed to ONE collective call, in bytes, summed over all peers.  Columns
+# of 10^9 rows are several GB per rank; they go out as a sequence of all-to-alls over row ranges
+# sized so that a call's whole send buffer (and whole receive buffer) stays below this.
+# Why: on this RCCL build a rank's send to itself delivers a message of 1 GiB intact, but of one of
+# 2 147 479 552 bytes (just under 2 GiB) everything from byte 1 073 741 824 on is lost -- the tail of
+# the receive buffer is left untouched -- through every entry point (all_to_all_single with or
+# without split sizes, the grouped send/recv form), so the loss is below torch
+# (tools/a2a_probe.py reproduces it).  The probe is a one-rank group, where the bytes per peer and the
+# bytes per call are the same number: which of the two the fault depends on is not known, so the
+# bound is applied to the call as a whole -- at most half a GiB per call, at most that divided by
+# the number of ranks per peer, a factor of two below the largest size seen intact.  That the bound
+# also protects exchanges between different ranks is extrapolated from that one-rank probe;
+# `verify=True` (TEMPO_SHUFFLE_VERIFY=1) checks every exchange by checksum.
 MAX_MESSAGE_BYTES = 1 << 29
 
 
@@ -222,6 +228,11 @@ def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
     gloo (tests and rehearsals; it has no list all-to-all): the round's views are gathered into
     one contiguous message for all_to_all_single and the answer is copied out again; device
     tensors are staged through host memory first."""
+    if staged.dtype not in (torch.uint8, torch.int32, torch.int64, torch.float32, torch.float64):
+        # element types the collectives do not take (int16 wire columns): the same bytes as uint8
+        es = staged.element_size()
+        return _exchange(staged.view(torch.uint8), got.view(torch.uint8), [v * es for v in send_l],
+                         [v * es for v in recv_l], rounds, rows_per_round * es, group)
     if _host_staged(group, staged):
         h_got = torch.empty(got.shape, dtype=got.dtype)
         for w in _exchange(staged.cpu(), h_got, send_l, recv_l, rounds, rows_per_round, group):
@@ -250,24 +261,149 @@ def _exchange(staged, got, send_l, recv_l, rounds, rows_per_round, group):
     return works
 
 
+def _checksum(t):
+    """Sum of a column's bytes as int64 (wraps; only ever compared with another such sum)."""
+    if t.numel() == 0:
+        return torch.zeros((), dtype=torch.int64, device=t.device)
+    return t.contiguous().view(torch.uint8).sum(dtype=torch.int64)
+
+
+class WirePlan:
+    """How a table's columns travel: the key together with the 0/1 mask columns in the narrowest of
+    1 / 2 / 4 bytes that holds (key bits + one bit per mask), every other integer column as its offset
+    from the global minimum in 4, 5, 6 or 8 bytes (a day of microseconds needs 5), everything else as
+    it is.  Elementwise, so it applies to rows in any order; decode(encode(x)) == x exactly."""
+
+    def __init__(self, key_bits, mask_cols, int_cols):
+        self.key_bits = key_bits          # bits of the key field
+        self.mask_cols = mask_cols        # positions (among the payload columns) folded into the key word
+        self.int_cols = int_cols          # {position: (minimum, bytes)}
+        width = key_bits + len(mask_cols)
+        self.key_dtype = torch.uint8 if width <= 8 else (torch.int16 if width <= 16 else torch.int32)
+
+    def bytes_per_row(self, columns):
+        total = torch.empty(0, dtype=self.key_dtype).element_size()
+        for i, c in enumerate(columns):
+            if i in self.mask_cols:
+                continue
+            total += self.int_cols[i][1] if i in self.int_cols else c.element_size()
+        return total
+
+    def encode(self, key, columns):
+        """[key, columns...] -> list of wire columns."""
+        word = key.to(torch.int32)
+        for b, i in enumerate(self.mask_cols):
+            word = word | (columns[i].to(torch.int32) << (self.key_bits + b))
+        wire = [word.to(self.key_dtype)]
+        for i, c in enumerate(columns):
+            if i in self.mask_cols:
+                continue
+            if i in self.int_cols:
+                lo, nbytes = self.int_cols[i]
+                if nbytes == 8:
+                    wire.append(c)
+                    continue
+                rel = c - lo
+                wire.append(rel.to(torch.int32))   # low four bytes (wraps into the sign bit: a bit pattern)
+                if nbytes == 5:
+                    wire.append((rel >> 32).to(torch.uint8))
+                elif nbytes == 6:
+                    wire.append((rel >> 32).to(torch.int16))
+            else:
+                wire.append(c)
+        return wire
+
+    def decode(self, wire, dtypes):
+        """Inverse of encode: (key int32, [columns in their own dtypes])."""
+        it = iter(wire)
+        word = next(it).to(torch.int32)
+        if self.key_dtype == torch.int16:
+            word = word & 0xffff
+        key = word & ((1 << self.key_bits) - 1) if self.key_bits < 31 else word
+        cols = [None] * len(dtypes)
+        for b, i in enumerate(self.mask_cols):
+            cols[i] = ((word >> (self.key_bits + b)) & 1).to(dtypes[i])
+        for i, dt in enumerate(dtypes):
+            if i in self.mask_cols:
+                continue
+            if i in self.int_cols:
+                lo, nbytes = self.int_cols[i]
+                if nbytes == 8:
+                    cols[i] = next(it)
+                    continue
+                rel = next(it).to(torch.int64) & 0xffffffff
+                if nbytes == 5:
+                    rel = rel | (next(it).to(torch.int64) << 32)
+                elif nbytes == 6:
+                    rel = rel | ((next(it).to(torch.int64) & 0xffff) << 32)
+                cols[i] = (rel + lo).to(dt)
+            else:
+                cols[i] = next(it)
+        return key.to(torch.int32), cols
+
+
+def plan_wire(key, columns, n_keys, group=None):
+    """WirePlan for one table from the global value ranges of its integer columns (one min / max
+    sweep per such column and one small all-reduce for the lot)."""
+    dev = key.device
+    ints = [i for i, c in enumerate(columns) if c.dtype in (torch.int64, torch.int32, torch.uint8)]
+    big = torch.iinfo(torch.int64).max
+    ends = torch.full((len(ints), 2), big, dtype=torch.int64, device=dev)   # (min, -max) per column
+    for j, i in enumerate(ints):
+        if columns[i].numel():
+            mn, mx = torch.aminmax(columns[i])
+            ends[j, 0], ends[j, 1] = mn.to(torch.int64), -mx.to(torch.int64)
+    if len(ints):
+        all_reduce(ends, dist.ReduceOp.MIN, group)
+    ends = ends.cpu().tolist()
+    key_bits = max(1, int(n_keys - 1).bit_length()) if n_keys > 1 else 1
+    mask_cols, int_cols = [], {}
+    for (lo, neg_hi), i in zip(ends, ints):
+        hi = -neg_hi
+        if lo > hi:          # no rows anywhere
+            lo = hi = 0
+        if columns[i].dtype == torch.uint8 and lo >= 0 and hi <= 1 and key_bits + len(mask_cols) < 31:
+            mask_cols.append(i)
+        elif columns[i].dtype == torch.int64:
+            span = hi - lo
+            nbytes = 4 if span < 2 ** 32 else (5 if span < 2 ** 40 else (6 if span < 2 ** 48 else 8))
+            int_cols[i] = (lo, nbytes)
+    return WirePlan(key_bits, mask_cols, int_cols)
+
+
 class PendingShuffle:
     """A key shuffle whose column exchanges are in flight.  wait() makes the current stream wait
     for them and returns (key_local, columns_local, send_counts, recv_counts).  The staged send
     buffers and the receive buffers stay referenced here until then."""
 
-    def __init__(self, works, staged, received, send_l, recv_l):
+    def __init__(self, works, staged, received, send_l, recv_l, wire=None, dtypes=None, sent_sums=None, group=None):
         self._works, self._staged, self._received = works, staged, received
         self.send_counts, self.recv_counts = send_l, recv_l
+        self._wire, self._dtypes, self._sent_sums, self._group = wire, dtypes, sent_sums, group
+        self.bytes_sent = sum(int(s.numel()) * s.element_size() for s in staged)
 
     def wait(self):
         for w in self._works:
             w.wait()
         self._works, self._staged = [], None
+        if self._sent_sums is not None:
+            # delivery check: over all ranks, the bytes that arrived add up to the bytes that left
+            got = torch.stack([_checksum(c) for c in self._received])
+            both = torch.stack([self._sent_sums, got])
+            all_reduce(both, dist.ReduceOp.SUM, self._group)
+            if not bool((both[0] == both[1]).all()):
+                bad = torch.nonzero(both[0] != both[1]).flatten().tolist()
+                raise RuntimeError("key shuffle: column(s) %r did not arrive as sent (checksums over all ranks "
+                                   "differ)" % (bad,))
+            self._sent_sums = None
+        if self._wire is not None:
+            key, cols = self._wire.decode(self._received, self._dtypes)
+            return key, cols, self.send_counts, self.recv_counts
         return self._received[0], self._received[1:], self.send_counts, self.recv_counts
 
 
 def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=None, owners=None,
-                         ts=None, halo=False):
+                         ts=None, halo=False, wire=None, verify=None):
     """Start sending every row to the rank that owns its key; returns a PendingShuffle.
 
     The device bucketing and the count exchange happen here (one small blocking read); the
@@ -282,7 +418,14 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     bracket at a slice boundary are then sent to the next slice's owner as well, and arrive
     after the rank's own rows.
     partition_fn / take_fn default to the HIP kernels; tests on CPU inject host equivalents.
+    wire: a WirePlan (plan_wire) -- the bucketed columns are narrowed before they travel and widened
+    again on arrival; the result is the same tensors as without it.
+    verify (default: TEMPO_SHUFFLE_VERIFY=1 in the environment): compare, in wait(), checksums of
+    what all ranks sent and received per column; a mismatch raises.
     """
+    import os
+    if verify is None:
+        verify = os.environ.get("TEMPO_SHUFFLE_VERIFY") == "1"
     world = dist.get_world_size(group)
     sliced = owners is not None and owners.slices is not None
     if sliced and ts is None:
@@ -308,7 +451,12 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
             if copies:
                 perm = perm[:int(counts.sum())]
             staged = [take_fn(c, perm) for c in cols]
+        if wire is not None:   # narrow the bucketed columns for the trip (elementwise: order does not matter)
+            staged = wire.encode(staged[0], staged[1:])
         parts.append((counts, staged))
+    dtypes = [c.dtype for c in columns]
+    if wire is not None:
+        cols = parts[0][1]   # the wire columns: what is exchanged from here on
     send = torch.stack([c.to(torch.int64) for c, _ in parts])          # [1 or 2][world]
     recv = torch.empty_like(send)
     for i in range(len(parts)):
@@ -321,7 +469,8 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
     works, staged_all, out_cols = [], [], []
     for ci, col in enumerate(cols):
         got = torch.empty(sum(n_recv), dtype=col.dtype, device=col.device)
-        rows_per_round = max(1, MAX_MESSAGE_BYTES // col.element_size())
+        # a round's call carries at most rows_per_round rows to each of `world` peers
+        rows_per_round = max(1, MAX_MESSAGE_BYTES // (col.element_size() * world))
         at = 0
         for i, (_, staged_cols) in enumerate(parts):
             if int(biggest[i]) == 0:  # nothing to move anywhere (all ranks agree on that)
@@ -334,11 +483,16 @@ def shuffle_by_key_start(key, columns, group=None, partition_fn=None, take_fn=No
         out_cols.append(got)
     total_send = [sum(v) for v in zip(*send_l)]
     total_recv = [sum(v) for v in zip(*recv_l)]
-    return PendingShuffle(works, staged_all, out_cols, total_send, total_recv)
+    sent_sums = None
+    if verify:
+        sent_sums = torch.stack([sum((_checksum(staged_cols[ci]) for _, staged_cols in parts),
+                                     torch.zeros((), dtype=torch.int64, device=key.device))
+                                 for ci in range(len(cols))])
+    return PendingShuffle(works, staged_all, out_cols, total_send, total_recv, wire, dtypes, sent_sums, group)
 
 
 def shuffle_by_key(key, columns, group=None, partition_fn=None, take_fn=None, owners=None, ts=None,
-                   halo=False):
+                   halo=False, wire=None, verify=None):
     """Send every row to the rank that owns its key (blocking form of shuffle_by_key_start).
     Returns (key_local, columns_local, send_counts, recv_counts)."""
-    return shuffle_by_key_start(key, columns, group, partition_fn, take_fn, owners, ts, halo).wait()
+    return shuffle_by_key_start(key, columns, group, partition_fn, take_fn, owners, ts, halo, wire, verify).wait()

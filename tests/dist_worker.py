@@ -50,6 +50,14 @@ def join_scenario(out_dir, rank, world):
                                             partition_fn=host_partition, take_fn=host_take, owners=plan,
                                             ts=T(tr[sl]), halo=True)
     assert (k1 == 0).any(), "every rank should own a slice of the hot key"
+    # narrowed columns (the NULL mask folded into the key byte) through the sliced, halo-carrying route
+    from tempo_amd.dist import plan_wire
+    qcols = [T(tr[sl]), T(va[sl]), T(rid[sl])]
+    wire = plan_wire(T(kr[sl]), qcols, 6)
+    assert wire.mask_cols == [1] and wire.bytes_per_row(qcols) == 1 + 4 + 4
+    k2w, (t2w, v2w, r2w), _, _ = shuffle_by_key(T(kr[sl]), qcols, partition_fn=host_partition, take_fn=host_take,
+                                                owners=plan, ts=T(tr[sl]), halo=True, wire=wire, verify=True)
+    assert torch.equal(k2w, k2) and torch.equal(t2w, t2) and torch.equal(v2w, v2) and torch.equal(r2w, r2)
     idx, _ = oracle.asof_join(k1.numpy(), t1.numpy(), k2.numpy(), t2.numpy(), valid_r=[None, v2.numpy()],
                               ts_partition_val=10, fraction=0.1)
     r2n = r2.numpy()
@@ -101,6 +109,23 @@ def main():
         torch.from_numpy(key[sl]), [torch.from_numpy(ts[sl]), torch.from_numpy(x[sl]), torch.from_numpy(rid[sl])],
         partition_fn=host_partition, take_fn=host_take)
     assert sum(recv) == k_loc.numel()
+    # the same shuffle with the columns narrowed for the trip (key in one byte, the timestamps and row
+    # ids as 4-byte offsets) and every exchange checked by checksum: the very same tensors arrive
+    from tempo_amd.dist import plan_wire
+    cols = [torch.from_numpy(ts[sl]), torch.from_numpy(x[sl]), torch.from_numpy(rid[sl])]
+    wire = plan_wire(torch.from_numpy(key[sl]), cols, nkeys)
+    assert wire.bytes_per_row(cols) == 1 + 4 + 8 + 4, wire.bytes_per_row(cols)
+    k_w, (ts_w, x_w, rid_w), send_w, recv_w = shuffle_by_key(torch.from_numpy(key[sl]), cols, partition_fn=host_partition,
+                                                             take_fn=host_take, wire=wire, verify=True)
+    assert torch.equal(k_w, k_loc) and torch.equal(ts_w, ts_loc) and torch.equal(x_w, x_loc) and torch.equal(rid_w, rid_loc)
+    assert send_w == send and recv_w == recv and ts_w.dtype == torch.int64 and k_w.dtype == torch.int32
+    # a key field wider than a byte travels as a 2-byte word (sent as raw bytes: the collectives have
+    # no 16-bit integer type)
+    wire16 = plan_wire(torch.from_numpy(key[sl]), cols, 5000)
+    assert wire16.key_dtype == torch.int16
+    k_h, (ts_h, x_h, rid_h), _, _ = shuffle_by_key(torch.from_numpy(key[sl]), cols, partition_fn=host_partition,
+                                                   take_fn=host_take, wire=wire16, verify=True)
+    assert torch.equal(k_h, k_loc) and torch.equal(ts_h, ts_loc) and torch.equal(x_h, x_loc) and torch.equal(rid_h, rid_loc)
     owners = {_lib.lib().tmp_key_owner(int(k), world) for k in k_loc.numpy()}
     assert owners <= {rank}, "a rank received a key it does not own"
     r = oracle.range_stats(k_loc.numpy(), ts_loc.numpy(), x_loc.numpy(), None, 30)
