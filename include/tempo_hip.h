@@ -221,7 +221,9 @@ typedef struct {
  * aggregates), so that a row's frame is the union of at most two such runs; a last sweep writes
  * every row's statistics where the row lies (out_perm[i] = i).  Tables with NaN or infinite
  * values, and everything else, take the ordered path.  The sums are atomic adds: last bits of
- * mean / sum / stddev / zscore may differ between two runs.
+ * mean / sum / stddev / zscore may differ between two runs.  A call that qualifies by its row and
+ * key counts asks for about 2.9 GiB of workspace more (tables for 2^24 cells, sized before the
+ * time range is known), whichever path it ends on.
  *
  * Two workspace sizes.  The plain one serves every table whose frames stay inside a block's
  * on-chip region (about 1280 rows back from a row, 256 same-second rows after it).  If some

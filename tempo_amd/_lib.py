@@ -15,6 +15,7 @@ TMP_MAX_JOIN_COLS = 16
 TMP_MAX_TAPS = 1024
 TMP_MAX_FEATURES = 64
 TMP_MAX_COLS = 64
+TMP_EINVAL = -1
 TMP_ECAPACITY = -5
 TMP_EWIDE = -6
 TMP_STATIC_PARTITION_MAX_ROWS = 1048576

@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "skew.h"
 
@@ -492,12 +494,17 @@ struct SideStream {
   hipStream_t st;
   hipEvent_t fork, join;
   bool ok, tried;
+  // held by a call from its fork record to its join wait: two host threads joining on one device
+  // would otherwise interleave their records and waits on the one event pair
+  std::mutex busy;
 };
 static SideStream *side_stream() {
   static SideStream per_dev[64];
+  static std::mutex create;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream &x = per_dev[dev];
+  std::lock_guard<std::mutex> guard(create);
   if (!x.tried) {
     x.tried = true;
     x.ok = hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking) == hipSuccess &&
@@ -519,8 +526,9 @@ struct SideJoin {
     SideStream *x = s;
     s = nullptr;
     hipError_t e = hipEventRecord(x->join, x->st);
-    if (e != hipSuccess) return e;
-    return hipStreamWaitEvent(st, x->join, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, x->join, 0);
+    x->busy.unlock();  // taken where the call forked
+    return e;
   }
   ~SideJoin() { (void)join(); }
 };
@@ -706,12 +714,13 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   // the kernels of the two sides then stretch each other, so per-kernel timings stop adding up.
   const char *two = getenv("TEMPO_JOIN_STREAMS");
   if (two && two[0] == '1' && a->n_right >= (1 << 20) && a->n_left >= (1 << 20)) side = side_stream();
+  if (side) side->busy.lock();
+  SideJoin side_join(side, st);  // from here on every way out joins the side stream and releases it
   if (side) {
     TMP_CHECK_HIP(hipEventRecord(side->fork, st));
     TMP_CHECK_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
     rst = side->st;
   }
-  SideJoin side_join(side, st);
   // a single left payload column is handed to the ordering step, which delivers it in (key, ts)
   // order straight into the output column; where it could not (rows already in order: no pass
   // ran) the merge fetches it through the row ids as it does for several columns

@@ -8,6 +8,22 @@
 
 namespace tmp {
 
+// Cell of a row: key id x buckets per key + the bucket's offset from the table's first bucket, formed
+// in 64 bits.  A key id outside the dictionary is read as the last key -- the rule of every sweep
+// over cells, so that all of them put such a row into the same cell; a bucket outside the table's
+// range (there is none on well-formed input) has no cell.
+__device__ __forceinline__ bool dense_cell_of(uint32_t key, int64_t bucket_off, uint32_t per_key, int64_t cells,
+                                              uint32_t *cell) {
+  if (bucket_off < 0 || bucket_off >= (int64_t)per_key) return false;
+  const uint64_t n_keys = (uint64_t)cells / per_key;
+  const uint64_t k = (uint64_t)key < n_keys ? (uint64_t)key : n_keys - 1;
+  const uint64_t g = k * per_key + (uint64_t)bucket_off;
+  if (g >= (uint64_t)cells) return false;
+  *cell = (uint32_t)g;
+  return true;
+}
+
+
 struct ColPtrs {
   const void *col[TMP_MAX_COLS];
   const uint8_t *valid[TMP_MAX_COLS];
@@ -116,8 +132,8 @@ __global__ __launch_bounds__(DH_THREADS) void dense_stats_kernel(const int32_t *
 #pragma unroll
     for (int r = 0; r < DH_ROWS; ++r) {
       if (row[r] >= n) continue;
-      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
-      if ((int64_t)g >= tab.cells || k[r] > 0xffffu) continue;  // a key id outside the dictionary: no cell
+      uint32_t g;
+      if (!dense_cell_of(k[r], floordiv_i64(t[r], dur) - bmin, per_key, tab.cells, &g)) continue;
       uint32_t slot = (g * 2654435761u) >> 23;  // top 9 bits
       bool found = false;
       for (int probe = 0; probe < DH_PROBES; ++probe) {

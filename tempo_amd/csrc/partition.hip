@@ -479,6 +479,9 @@ static void *g_scratch_ptr[kMaxDevices];  // [device ordinal], filled on the fir
 extern "C" int tmp_hash_partition_static(const tmp_partition_args *a, void *stream) {
   clear_error();
   TMP_REQUIRE(a != nullptr, TMP_EINVAL, "tmp_hash_partition_static: null args");
+  // the argument errors tmp_hash_partition reports come first, under the same code
+  TMP_REQUIRE(a->n >= 0, TMP_EINVAL, "tmp_hash_partition_static: row count must be in [0, 2^31)");
+  TMP_REQUIRE(a->n == 0 || (a->key && a->out_perm), TMP_EINVAL, "tmp_hash_partition_static: null pointer");
   TMP_REQUIRE(a->n <= kStaticMaxRows, TMP_ECAPACITY,
               "tmp_hash_partition_static: %lld rows exceed the built-in scratch (at most %lld rows); "
               "use tmp_hash_partition with a workspace", (long long)a->n, (long long)kStaticMaxRows);

@@ -181,7 +181,12 @@ void rs_cells_plan(const tmp_range_stats_args *a, Workspace &ws, RsCellsPlan *p)
   if (!a->any_order || a->x_is_i64 || a->n < (getenv("TEMPO_DENSE_MIN_ROWS") ? dense_min_rows() : kCellMinRows) ||
       plan_keys(a->key, a->n_keys) > kCellKeys || getenv("TEMPO_NO_RANGE_CELLS"))
     return;
-  const size_t c = (size_t)kCellMax;
+  // The tables are sized before the table's time range is known (the caller brings the workspace):
+  // for every cell the path may take, about 184 bytes each -- 2.9 GiB at kCellMax.  A call that sets
+  // any_order on 2^22 rows or more asks for that much even if it ends on the ordered path.
+  const int64_t bound = kCellMax;
+  const size_t c = (size_t)bound;
+  p->cap = bound;
   p->planned = 1;
   p->sum = ws.take<double>(c); p->total = ws.take<double>(c); p->acc = ws.take<double>(c); p->lin = ws.take<double>(c);
   p->mn = ws.take<uint64_t>(c); p->mx = ws.take<uint64_t>(c);
@@ -195,7 +200,7 @@ int rs_cells_try(const tmp_range_stats_args *a, RsCellsPlan &p, const RangeInfo 
   if (!p.planned || sorted_mode(r) == 0) return TMP_OK;
   const int64_t nk = plan_keys(a->key, a->n_keys);
   const uint64_t per_key = (uint64_t)r.prim_max - (uint64_t)r.prim_min + 1;  // seconds first .. last
-  if (per_key < 1 || per_key > (uint64_t)kCellMax || (uint64_t)nk * per_key > (uint64_t)kCellMax) return TMP_OK;
+  if (per_key < 1 || per_key > (uint64_t)p.cap || (uint64_t)nk * per_key > (uint64_t)p.cap) return TMP_OK;
   StatTab tab;
   memset(&tab, 0, sizeof(tab));
   tab.cells = (int64_t)((uint64_t)nk * per_key);

@@ -162,6 +162,7 @@ int rs_wide_run(const uint64_t *comp, const T *xs, int64_t n, const Layout &lay,
 // step's scan read them, seconds as the primary key) allow, and says so in *done.
 struct RsCellsPlan {
   int planned;
+  int64_t cap;  // cells the tables were sized for
   double *sum, *total, *acc, *lin;
   uint64_t *mn, *mx;
   uint32_t *rows, *cnt;

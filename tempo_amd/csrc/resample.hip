@@ -725,8 +725,8 @@ __global__ __launch_bounds__(DH_THREADS) void dense_mean_kernel(const int32_t *k
 #pragma unroll
     for (int r = 0; r < DH_ROWS; ++r) {
       if (row[r] >= n) continue;
-      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
-      if ((int64_t)g >= tab.cells || k[r] > 0xffffu) continue;  // a key id outside the dictionary: no cell
+      uint32_t g;
+      if (!dense_cell_of(k[r], floordiv_i64(t[r], dur) - bmin, per_key, tab.cells, &g)) continue;
       uint32_t slot = (g * 2654435761u) >> 22;  // top 10 bits
       bool found = false;
       for (int probe = 0; probe < DH_PROBES; ++probe) {
@@ -965,8 +965,8 @@ __global__ __launch_bounds__(DH_THREADS) void dense_pick_kernel(const int32_t *k
 #pragma unroll
     for (int r = 0; r < DH_ROWS; ++r) {
       if (row[r] >= n) continue;
-      const uint32_t g = k[r] * per_key + (uint32_t)(floordiv_i64(t[r], dur) - bmin);
-      if ((int64_t)g >= tab.cells || k[r] > 0xffffu) continue;  // a key id outside the dictionary: no cell
+      uint32_t g;
+      if (!dense_cell_of(k[r], floordiv_i64(t[r], dur) - bmin, per_key, tab.cells, &g)) continue;
       const uint64_t code = code_i64(t[r]);
       if (SWEEP == 1 && tab.ext[g] != code) continue;
       uint32_t slot = (g * 2654435761u) >> 22;  // top 10 bits

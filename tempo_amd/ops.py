@@ -693,6 +693,39 @@ _ARROW_KINDS = {"i32": (_lib.ARROW_I32, torch.int32), "i64": (_lib.ARROW_I64, to
                 "f64": (_lib.ARROW_F64, torch.float64), "i64_raw": (_lib.ARROW_I64_RAW, torch.int64)}
 
 
+def _arrow_range_check(arr, kind):
+    """The conversions that can lose values -- uint64 into int64, 64-bit integers into int32,
+    second / millisecond timestamps scaled to microseconds -- are refused when a value of the
+    column does not survive them (Spark would keep the value or raise; wrapping silently is
+    neither).  One min / max over the column, and only for those types."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    t = arr.type
+    if pa.types.is_dictionary(t):
+        t = t.index_type
+    lo, hi = -2 ** 63, 2 ** 63 - 1
+    scale = 1
+    if kind == "i32" and pa.types.is_integer(t) and t.bit_width == 64:
+        lo, hi = -2 ** 31, 2 ** 31 - 1
+    elif kind in ("i64", "i64_raw", "i32") and pa.types.is_uint64(t):
+        if kind == "i32":
+            lo, hi = -2 ** 31, 2 ** 31 - 1
+    elif kind == "i64" and pa.types.is_timestamp(t) and t.unit in ("s", "ms"):
+        scale = 1_000_000 if t.unit == "s" else 1_000
+    else:
+        return
+    if len(arr) == 0 or arr.null_count == len(arr):
+        return
+    values = arr.indices if pa.types.is_dictionary(arr.type) and hasattr(arr, "indices") else arr
+    if pa.types.is_timestamp(t):
+        values = values.cast(pa.int64())
+    mm = pc.min_max(values)
+    vmin, vmax = mm["min"].as_py(), mm["max"].as_py()
+    if vmin * scale < lo or vmax * scale > hi:
+        raise OverflowError(f"arrow_import: column of type {arr.type} holds values ({vmin} .. {vmax}) that do not "
+                            f"fit the device column ({kind}) after conversion")
+
+
 def arrow_import(arr, kind, device=None):
     """A pyarrow Array or ChunkedArray to a device column through the Arrow C data interface: the
     value buffers are copied from where Arrow holds them, chunk by chunk, into one device tensor.
@@ -700,6 +733,7 @@ def arrow_import(arr, kind, device=None):
     kind: "i32" | "i64" (timestamps -> microseconds) | "i64_raw" (timestamps as stored) | "f64".
     Dictionary arrays give their indices.  Returns (values, valid uint8 or None, null_count)."""
     code, dtype = _ARROW_KINDS[kind]
+    _arrow_range_check(arr, kind)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     chunks = arr.chunks if hasattr(arr, "chunks") else [arr]
     n = sum(len(c) for c in chunks)

@@ -58,3 +58,18 @@ def test_many_wide_key_columns_do_not_collide():
     back = decode(acodes)
     for j in range(ncol):
         assert back[j].to_pylist() == vals[:, j].tolist()
+
+
+def test_arrow_import_refuses_values_that_would_wrap():
+    """uint64 beyond int64, 64-bit indices beyond int32 and second / millisecond timestamps whose
+    microseconds overflow are refused before anything is copied (no device needed to find out)."""
+    from tempo_amd import ops
+    with pytest.raises(OverflowError):
+        ops.arrow_import(pa.array([1, 2 ** 63 + 1], type=pa.uint64()), "i64")
+    with pytest.raises(OverflowError):
+        ops.arrow_import(pa.array([0, 2 ** 31], type=pa.int64()), "i32")
+    with pytest.raises(OverflowError):
+        ops.arrow_import(pa.array([9_223_372_036_855], type=pa.timestamp("s")), "i64")   # x 10^6 > 2^63
+    with pytest.raises(OverflowError):
+        ops.arrow_import(pa.chunked_array([pa.array([1, None], type=pa.timestamp("ms")),
+                                           pa.array([-9_223_372_036_854_776], type=pa.timestamp("ms"))]), "i64")

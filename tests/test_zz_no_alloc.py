@@ -57,3 +57,31 @@ def test_static_scratch_partition_rejects_oversize():
     perm, cnt = ops.hash_partition(key, 4, static_scratch=True)
     perm_w, cnt_w = ops.hash_partition(key, 4)
     assert torch.equal(perm, perm_w) and torch.equal(cnt, cnt_w)
+
+
+def test_static_scratch_partition_takes_no_device_memory():
+    """Device memory as the driver counts it (hipMemGetInfo, which sees every hipMalloc, not only
+    torch's) is the same before and after a call made with outputs that exist already; the first
+    call on a device may resolve the scratch array's address, so one warm-up call comes first."""
+    import ctypes as C
+    from tempo_amd import _lib
+    n, parts = 400_000, 8
+    key = (torch.arange(n, dtype=torch.int32, device="cuda") * 7919) % 1000
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(parts, dtype=torch.int64, device="cuda")
+    a = _lib.PartitionArgs()
+    a.n, a.key, a.n_parts, a.out_perm, a.out_counts = n, key.data_ptr(), parts, perm.data_ptr(), counts.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().tmp_hash_partition_static(C.byref(a), stream), "warm-up")
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        _lib.check(_lib.lib().tmp_hash_partition_static(C.byref(a), stream), "tmp_hash_partition_static")
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    assert int(counts.sum()) == n
+    # argument errors come under the code tmp_hash_partition gives them, before any capacity test
+    a.n = -1
+    assert _lib.lib().tmp_hash_partition_static(C.byref(a), stream) == _lib.TMP_EINVAL
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    assert _lib.lib().tmp_hash_partition(C.byref(a), ws.data_ptr(), ws.numel(), stream) == _lib.TMP_EINVAL
