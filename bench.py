@@ -162,7 +162,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per operator per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=48_000_000, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
+                    help="rows per operator of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-shuffled", action="store_true",
                     help="skip the extra withRangeStats run on a row-permuted tick table")
@@ -528,7 +529,14 @@ def cpu_baseline(sample_rows):
         list(pool.map(ticks_one, tick_parts))
         t2 = time.perf_counter()
     total = t2 - t0
+    mem_total_gib = None
+    try:
+        with open("/proc/meminfo") as f:
+            mem_total_gib = round(int(f.readline().split()[1]) / 2 ** 20, 1)
+    except (OSError, ValueError, IndexError):
+        pass
     return dict(value=(nl + nr + sample_rows) / total, unit="rows/s", cores=threads, kind="port",
+                host_mem_total_gib=mem_total_gib,
                 sample=("C oracle (oracle/tempo_oracle.c), %d threads over key shards: asofJoin %d+%d rows "
                         "%.2f s, withRangeStats %d rows %.2f s; same distributions as the GPU workload, "
                         "1/%d of its rows per operator (bounded so that the default run stays within minutes; "
