@@ -116,7 +116,7 @@ def gen_ticks(dev, n, n_keys, seed, shards=1):
 # algorithmic bytes one launch of a kernel moves, per row it processes (every input read once,
 # every output written once)
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                "r02_bench1b_pmc_traffic.json")
+                                "r03_bench1b_pmc_traffic.json")
 
 COPY_CEILING_FILE = os.path.join(os.path.dirname(PMC_TRAFFIC_FILE), "r01_copy_ceiling.json")
 

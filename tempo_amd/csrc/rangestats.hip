@@ -435,13 +435,29 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     constexpr int kHalf = RK_SB / 2;
     const bool head_half = sa != sb && (a % RK_SB) < kHalf;   // head stops at the middle, + second half
     const bool tail_half = sa != sb && (b % RK_SB) >= kHalf;  // first half + tail from the middle on
-    const int head_end = sa == sb ? b : (head_half ? sa * RK_SB + kHalf - 1 : (sa + 1) * RK_SB - 1);
-    const int tail_begin = sa == sb ? b + 1 : (tail_half ? sb * RK_SB + kHalf : sb * RK_SB);
+    // both walks are at most half a sub-block long: a frame inside one sub-block is cut after its
+    // first four slots
+    const int head_end = sa == sb ? (b < a + kHalf - 1 ? b : a + kHalf - 1)
+                                  : (head_half ? sa * RK_SB + kHalf - 1 : (sa + 1) * RK_SB - 1);
+    const int tail_begin = sa == sb ? head_end + 1 : (tail_half ? sb * RK_SB + kHalf : sb * RK_SB);
     if constexpr (!kInt) {
       if (!s.nonfinite) {
-      // every staged value is finite and NULL slots hold NaN: no per-slot tests needed
-      for (int e = a; e <= head_end; ++e) slot_add_f64(s.x[xi(e)], pivot, sd, sq, dc, mn, mx);
-      for (int e = tail_begin; e <= b; ++e) slot_add_f64(s.x[xi(e)], pivot, sd, sq, dc, mn, mx);
+        // every staged value is finite and NULL slots hold NaN: no per-slot tests needed.  All
+        // eight slots are read at once (one beyond a walk reads as NULL and adds nothing) instead
+        // of one LDS round trip per step of two loops whose lengths differ from lane to lane.
+        double hv[kHalf], tv[kHalf];
+#pragma unroll
+        for (int u = 0; u < kHalf; ++u) {
+          const int eh = a + u, et = tail_begin + u;
+          hv[u] = s.x[xi(eh < RK_CAP ? eh : RK_CAP - 1)];
+          tv[u] = s.x[xi(et < RK_CAP ? et : RK_CAP - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < kHalf; ++u)
+          slot_add_f64(a + u <= head_end ? hv[u] : MinMax<double>::null_slot(), pivot, sd, sq, dc, mn, mx);
+#pragma unroll
+        for (int u = 0; u < kHalf; ++u)
+          slot_add_f64(tail_begin + u <= b ? tv[u] : MinMax<double>::null_slot(), pivot, sd, sq, dc, mn, mx);
       }
     }
     if (kInt || s.nonfinite) {

@@ -2,7 +2,7 @@
 # rocprofv3 passes over bench.py at the headline workload: kernel trace + stats, then FETCH_SIZE and
 # WRITE_SIZE in passes of their own; the summaries go to gpurun_out/bench_prof/ (copy them to profiles/).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/bench_prof

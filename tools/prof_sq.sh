@@ -3,7 +3,7 @@
 # instructions per kind, LDS bank-conflict cycles, share of vector issue slots filled) to
 # gpurun_out/sq_prof/ (copy it to profiles/).  Needs the kernel stats of tools/prof_bench.sh.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/sq_prof
