@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
   for (int r = 0; r < kMergeRows; ++r) {
     const int64_t i = tile + r * kBlock + threadIdx.x;
     wl_pre[r] = i < tile_end ? comp_l[i] : 0ull;
-    src_pre[r] = i < tile_end ? perm_l[i] : 0u;
+    src_pre[r] = (i < tile_end && perm_l) ? perm_l[i] : 0u;
   }
 #pragma unroll
   for (int r = 0; r < kMergeRows; ++r) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     for (int mm = 0; mm < 4; ++mm)
       jpre[mm] = (same && mm < n_masks) ? lastnn[(size_t)mm * n_right + jr] : -1;
     if (sorted_output && out_perm) {
-      out_perm[i] = (int32_t)src_row;
+      if (perm_l) out_perm[i] = (int32_t)src_row;  // null: the ordering step left the row ids in out_perm itself
       if (out_key) out_key[i] = (int32_t)key_l;
       if (out_ts) out_ts[i] = lay.prim_of(wl);
     }
@@ -622,6 +622,9 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   asof_plan(a, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE,
               "tmp_asof_join: workspace too small (%zu < %zu)", workspace_bytes, ws.off);
+  // the left side's second row-id buffer is the caller's out_perm (when that is aligned like the
+  // workspace's own): an ordering that ends there has put the row ids where they belong
+  if (a->sorted_output && a->out_perm && ((uintptr_t)a->out_perm & 255) == 0) p.lb.idx[1] = (uint32_t *)a->out_perm;
   if (a->n_right == 0 && !a->sorted_output) {  // nothing to match: every index is -1, everything is missing
     int grid = grid_for(a->n_left, kBlock * 4, 8192);
     TMP_LAUNCH(fill_i32_kernel, dim3(grid), dim3(kBlock), st, a->out_idx, a->n_left * (1 + a->n_masks), -1);
@@ -766,15 +769,19 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(merge_bounds_kernel, dim3((grid + 1 + kBlock - 1) / kBlock), dim3(kBlock), st, lo.comp, a->n_left, ro.comp,
              a->n_right, lay.low_bits, kBlock * kMergeRows, (int64_t)grid, p.block_bounds);
+  // the left row ids: not read at all when they already lie in out_perm and no left payload has to be
+  // fetched through them (record mode in left row order needs them as destinations)
+  const uint32_t *perm_l = lo.perm;
+  if (a->sorted_output && !left_ref && (const void *)lo.perm == (const void *)a->out_perm && jc.n_left == 0) perm_l = nullptr;
   {
     ProfScope ps("asof_merge_kernel", st);
     if (jc.n <= 4 && a->n_masks <= 4)
-      hipLaunchKernelGGL((asof_merge_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+      hipLaunchKernelGGL((asof_merge_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, lo.comp, perm_l, a->n_left,
                          ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
                          a->out_missing, a->sorted_output, left_ref ? nullptr : a->out_perm, left_ref ? nullptr : a->out_key,
                          left_ref ? nullptr : a->out_ts, jc, p.block_bounds, cmask);
     else
-      hipLaunchKernelGGL((asof_merge_kernel<0, 0>), dim3(grid), dim3(kBlock), 0, st, lo.comp, lo.perm, a->n_left,
+      hipLaunchKernelGGL((asof_merge_kernel<0, 0>), dim3(grid), dim3(kBlock), 0, st, lo.comp, perm_l, a->n_left,
                          ro.comp, ro.perm, a->n_right, lay, a->n_masks, p.lastnn, sp, a->out_idx,
                          a->out_missing, a->sorted_output, left_ref ? nullptr : a->out_perm, left_ref ? nullptr : a->out_key,
                          left_ref ? nullptr : a->out_ts, jc, p.block_bounds, cmask);

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     b = lo - 1;
   }
   RTICK();
-  o.perm[i] = (int32_t)perm[i];
+  if (perm) o.perm[i] = (int32_t)perm[i];  // null: the ordering step left the row ids in o.perm itself
   const bool open_left = a == 0 && rs > 0;          // the frame may start before the region
   const bool open_right = b == len - 1 && re < n;   // peers may continue after the region
   bool slow = open_left || open_right || krel >= RK_SAT;
@@ -615,7 +615,8 @@ static int rs_column(const OrderResult &res, const T *xs, int64_t n, const Layou
   const int n_tiles = (int)((n + RK_ROWS - 1) / RK_ROWS);
   int grid = (n_tiles + 7) / 8 * 8;
   TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
-  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, res.perm, xs, n, lay, w, o,
+  const uint32_t *perm = (const void *)res.perm == (const void *)o.perm ? nullptr : res.perm;
+  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, perm, xs, n, lay, w, o,
              deferred_flag, n_tiles);
   TMP_CHECK_HIP(hipGetLastError());
   int32_t deferred = 0;
@@ -716,6 +717,9 @@ extern "C" int tmp_range_stats(const tmp_range_stats_args *a, void *workspace,
   RsPlan p;
   rs_plan(a, ws, &p, have_wide);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_range_stats: workspace too small");
+  // the second row-id buffer of the ordering step is the caller's out_perm: when the order ends up there
+  // (a single pass does), the row ids are where they belong and the kernel neither reads nor copies them
+  if (((uintptr_t)a->out_perm & 255) == 0) p.ob.idx[1] = (uint32_t *)a->out_perm;  // aligned like the workspace's own
   hipStream_t st = (hipStream_t)stream;
   RangeInfo range;
   const RangeInfo *known = nullptr;
@@ -769,6 +773,7 @@ extern "C" int tmp_range_stats_cols(const tmp_range_stats_cols_args *a, void *wo
   RsColsPlan p;
   rs_cols_plan(a, ws, &p, have_wide);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_range_stats_cols: workspace too small");
+  if (((uintptr_t)a->out_perm & 255) == 0) p.ob.idx[1] = (uint32_t *)a->out_perm;  // see tmp_range_stats
   hipStream_t st = (hipStream_t)stream;
   // one ordering for all columns: column c's "not NULL" flag rides in bit c of the sort words and
   // its values travel with the rows
