@@ -134,7 +134,8 @@ KERNEL_BYTES_PER_ROW = {
     "radix_scatter_kernel": 24.0,     # (8 B sort word + 4 B row id) in and out
     "radix_hist_kernel": 8.0,         # sort word in
     "radix_hist_kernel+words": 20.0,  # first pass: key 4 + ts 8 in (+ mask bytes), sort word 8 out
-    "range_stats_kernel<T>": 81.0,    # word 8 + metric 8 + row id 4 in; 7 stats x 8 + perm 4 + flags 1 out
+    "range_stats_kernel<T>": 73.0,    # word 8 + metric 8 in; 7 stats x 8 + flags 1 out (the row ids are ordered
+                                      # straight into the caller's array by the sort, the kernel does not touch them)
     "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out
     "radix_scatter_kernel+payload": 40.0,  # pair 12 + one 8 B payload column, in and out
     "pack_rows_kernel": 56.0,         # 3 x 8 B columns in, one 32 B record out

@@ -22,6 +22,8 @@ SEEDS = FOUND + [7 * 1_000_003 + i for i in range(60)]
 # to three rows left one half of the key dictionary without right rows, whose empty validity masks
 # were then taken for one and the same
 EXTRA_SEEDS = [4000104, 4000211] + [9 * 1_000_003 + i for i in range(30)]
+# third pool: joins of two tables that are both in order (the one-sweep join)
+ORDERED_SEEDS = [1_000_003 + i for i in range(60)]
 
 
 @pytest.fixture(scope="module")
@@ -50,5 +52,13 @@ def test_operator_fuzz_case(fz, case_seed, monkeypatch):
     rng = np.random.default_rng(case_seed)
     weights = np.array([c[2] for c in fz.CASES], dtype=np.float64)
     name, fn, _ = fz.CASES[int(rng.choice(len(fz.CASES), p=weights / weights.sum()))]
+    fn(rng)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case_seed", ORDERED_SEEDS)
+def test_operator_fuzz_case_ordered_join(fz, case_seed):
+    rng = np.random.default_rng(case_seed)
+    name, fn, _ = fz.ORDERED_CASES[int(rng.choice(len(fz.ORDERED_CASES), p=np.full(len(fz.ORDERED_CASES), 1.0 / len(fz.ORDERED_CASES))))]
     fn(rng)
     torch.cuda.synchronize()

@@ -203,6 +203,95 @@ def case_asof(rng):
     return desc + " [table cols=%d skip=%s]" % (ncol, skip)
 
 
+def case_asof_ordered(rng):
+    """Both sides in (key, ts[, seq NULLS FIRST]) order: the one-sweep join. Side sizes far apart,
+    masks with long NULL runs, few timestamps per key (many ties), skew brackets, records and
+    fused-table output, the left table by reference."""
+    n_keys = int(rng.choice([1, 2, 40, 5000, 300_000]))
+    nl, nr = draw_size(rng), draw_size(rng)
+    lop = rng.random()
+    if lop < 0.2:
+        nl = int(rng.integers(1, 40))         # a handful of left rows over a long right side
+    elif lop < 0.4:
+        nr = int(rng.integers(1, 40))
+    step_us = int(rng.choice([1, 1000, 1_000_000, 250_000]))
+    span = int(rng.choice([3, 30, 5_000, 3_000_000]))
+    kl = rng.integers(0, n_keys, nl).astype(np.int32)
+    kr = rng.integers(0, n_keys, nr).astype(np.int32)
+    split = rng.random()
+    if n_keys > 1 and split < 0.25:           # the sides share few keys
+        kl, kr = np.minimum(kl, n_keys // 2).astype(np.int32), np.maximum(kr, n_keys // 2 - 1).astype(np.int32)
+    elif n_keys > 1 and split < 0.5:          # one heavy key
+        kl = np.where(rng.random(nl) < 0.8, n_keys // 3, kl).astype(np.int32)
+        kr = np.where(rng.random(nr) < 0.8, n_keys // 3, kr).astype(np.int32)
+    shift = int(rng.choice([0, 0, span // 2 + 1, -(span // 2 + 1)]))  # right side partly before / after the left
+    tl = BASE + rng.integers(0, span, nl) * step_us
+    tr = BASE + (rng.integers(0, span, nr) + shift) * step_us
+    seq, seqv = draw_seq(rng, nr)
+    if seq is not None and seqv is None:
+        seqv = np.ones(nr, np.uint8)
+    masks = [m for m in (draw_mask(rng, nr) for _ in range(int(rng.integers(0, 5)))) if m is not None][:4]
+    o = np.lexsort((tl, kl))
+    kl, tl = kl[o], tl[o]
+    o = np.lexsort((tr, kr)) if seq is None else np.lexsort((np.where(seqv == 1, seq, -10**9), tr, kr))
+    kr, tr = kr[o], tr[o]
+    if seq is not None:
+        seq, seqv = seq[o], seqv[o]
+    skew = rng.random() < 0.35
+    tpv = (int(rng.choice([1, 3, 10, 600])) if rng.random() < 0.6 else float(rng.choice([0.5, 7.5]))) if skew else None
+    frac = float(rng.choice([0.1, 0.5, 0.9]))
+    secs = bool(rng.random() < 0.15)
+    if secs:
+        tl, tr = tl // 1_000_000, tr // 1_000_000
+    desc = LAST["desc"] = "asof_ordered nl=%d nr=%d keys=%d span=%d step=%d shift=%d masks=%d seq=%s skew=%r frac=%g secs=%s" % (
+        nl, nr, n_keys, span, step_us, shift, len(masks), seq is not None, tpv, frac, secs)
+    if nl == 0 or nr == 0:
+        return desc + " [skipped: empty]"
+    use_key = n_keys > 1 or rng.random() < 0.5
+    a = (dev(kl) if use_key else None, dev(tl), dev(kr) if use_key else None, dev(tr), n_keys)
+    h = (host(kl) if use_key else None, host(tl), host(kr) if use_key else None, host(tr), n_keys)
+    kw = dict(ts_is_seconds=secs, ts_partition_val=tpv, fraction=frac)
+    if rng.random() < 0.4:
+        row, midx, miss = ops.asof_join(*a, seq_r=dev(seq), seq_r_valid=dev(seqv), masks=[dev(m) for m in masks], **kw)
+        erow, emidx, emiss = orc.asof_join(*h, seq_r=host(seq), seq_r_valid=host(seqv), masks=[host(m) for m in masks], **kw)
+        eq(row, erow, "row index")
+        eq(midx.reshape(len(masks), nl), emidx, "skip-null indices")
+        eq(miss, emiss, "missing flags")
+        return desc + " [records]"
+    ncol = int(rng.integers(1, 7))
+    rcols = [rng.normal(0, 1, nr) if rng.random() < 0.7 else rng.integers(-9, 9, nr) for _ in range(ncol)]
+    col_mask = [None if (not masks or rng.random() < 0.3) else int(rng.integers(0, len(masks))) for _ in range(ncol)]
+    lcols = [rng.normal(0, 1, nl) for _ in range(int(rng.integers(0, 3)))]
+    skip = bool(rng.random() < 0.7)
+    by_ref = bool(rng.random() < 0.5)
+    dmasks, hmasks = [dev(m) for m in masks], [host(m) for m in masks]
+    dl = [dev(c) for c in lcols]
+    j = ops.asof_join_table(*a, dl, [dev(c) for c in rcols],
+                            [None if s is None else dmasks[s] for s in col_mask], skip_nulls=skip,
+                            seq_r=dev(seq), seq_r_valid=dev(seqv), left_by_reference=by_ref, **kw)
+    e = orc.asof_join_table(*h, [host(c) for c in lcols], [host(c) for c in rcols],
+                            [None if s is None else hmasks[s] for s in col_mask], skip_nulls=skip,
+                            seq_r=host(seq), seq_r_valid=host(seqv), **kw)
+    if by_ref and not j["in_place"] and tpv is None:
+        raise AssertionError("an ordered left table was not used by reference")
+    if j["in_place"]:
+        eq(e["perm"], np.arange(nl), "expected order is the input order")
+        if lcols and j["left"][0].data_ptr() != dl[0].data_ptr():
+            raise AssertionError("left columns were copied")
+    else:
+        eq(j["perm"], e["perm"], "perm")
+    if use_key:
+        eq(j["key"], e["key"], "key")
+    eq(j["ts"], e["ts"], "ts")
+    for c in range(len(lcols)):
+        eq(j["left"][c], e["left"][c], "left column %d" % c)
+    for c in range(ncol):
+        ok = e["right"][c][1].numpy() != 0
+        eq(j["right"][c][1], e["right"][c][1], "right validity %d" % c)
+        eq(j["right"][c][0].cpu()[torch.from_numpy(ok)], e["right"][c][0][torch.from_numpy(ok)], "right column %d" % c)
+    return desc + " [table cols=%d skip=%s by_ref=%s in_place=%s]" % (ncol, skip, by_ref, j["in_place"])
+
+
 def case_range_stats(rng):
     n_keys = int(rng.choice([1, 3, 40, 1000]))
     n = draw_size(rng)
@@ -458,6 +547,8 @@ CASES = [("asof", case_asof, 4), ("range_stats", case_range_stats, 3), ("ema", c
          ("resample", case_resample, 2), ("grouped_stats", case_grouped, 2), ("interpolate", case_interpolate, 1)]
 # a pool of its own (--extra), so that the case a seed of the first pool names stays the same
 EXTRA_CASES = [("asof_wide", case_asof_wide, 1), ("partition", case_partition, 1), ("write_layout", case_write_layout, 1)]
+# a third pool (--ordered): joins of two tables that are both in order
+ORDERED_CASES = [("asof_ordered", case_asof_ordered, 1)]
 
 
 def main():
@@ -468,11 +559,12 @@ def main():
     ap.add_argument("--case-seed", type=int, default=0, help="run this one case again (the seed a log line names)")
     ap.add_argument("--extra", action="store_true",
                     help="the second pool: joins of tables wider than one sort word, shuffle routing, write layout")
+    ap.add_argument("--ordered", action="store_true", help="the third pool: joins of two tables already in (key, ts) order")
     ap.add_argument("--only", default="", help="comma-separated operator names")
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "fuzz_ops.log"))
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.log), exist_ok=True)
-    pool = [c for c in (EXTRA_CASES if args.extra else CASES) if not args.only or c[0] in args.only.split(",")]
+    pool = [c for c in (ORDERED_CASES if args.ordered else EXTRA_CASES if args.extra else CASES) if not args.only or c[0] in args.only.split(",")]
     weights = np.array([c[2] for c in pool], dtype=np.float64)
     weights /= weights.sum()
     t_end = time.time() + args.seconds
