@@ -134,6 +134,11 @@ KERNEL_BYTES_PER_ROW = {
     "radix_scatter_kernel": 24.0,     # (8 B sort word + 4 B row id) in and out
     "radix_hist_kernel": 8.0,         # sort word in
     "radix_hist_kernel+words": 20.0,  # first pass: key 4 + ts 8 in (+ mask bytes), sort word 8 out
+    "radix_hist_kernel+keys": 4.0,    # first pass of a time-ordered feed: the key column alone
+    # ... and its scatter, which builds the words: key 4 + ts 8 + NULL flag 1 + metric 8 in, word 8 +
+    # row id 4 + metric 8 out (without a travelling column: 13 in, 12 out)
+    "radix_scatter_kernel+words+carried": 41.0,
+    "radix_scatter_kernel+words": 25.0,
     "range_stats_kernel<T>": 73.0,    # word 8 + metric 8 in; 7 stats x 8 + flags 1 out (the row ids are ordered
                                       # straight into the caller's array by the sort, the kernel does not touch them)
     "gather_kernel<uint64_t>": 21.0,  # idx 4 + value 8 in, value 8 + flag 1 out

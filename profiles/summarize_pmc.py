@@ -23,10 +23,14 @@ def short(name):
         return None
     base, args = m.group(1), (m.group(3) or "")
     if base == "radix_scatter_kernel":
-        npay = args.split(",")[2].strip()
+        parts = [a.strip() for a in args.split(",")]
+        npay = parts[2]
+        if len(parts) > 6 and parts[6] in ("true", "1"):  # the pass that builds the sort words itself
+            base += "+words"
         return base + ("+carried" if npay.startswith("-") else "+payload" if npay != "0" else "")
     if base == "radix_hist_kernel":
-        return base + ("+words" if args.split(",")[-1].strip() in ("true", "1", "2") else "")
+        gen = args.split(",")[-1].strip()
+        return base + ("+keys" if gen == "3" else "+words" if gen in ("true", "1", "2") else "")
     if base == "range_stats_kernel":
         return "range_stats_kernel<T>"
     if base == "gather_kernel":

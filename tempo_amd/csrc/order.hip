@@ -273,6 +273,17 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   return w;
 }
 
+// The sort word of a row without a sequence column, from its loaded values (key id, time, NULL
+// mask bits): what make_word gives for plain (not bucketed) words.
+__device__ __forceinline__ uint64_t plain_word(const Layout &lay, int64_t ts, uint32_t key, uint32_t mask_bits) {
+  const int64_t p = lay.prim_div == 1 ? ts : floordiv_i64(ts, lay.prim_div);
+  uint64_t rel = (uint64_t)(p - lay.prim_min);
+  if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
+  uint64_t w = (rel << lay.prim_shift()) | mask_bits;
+  if (lay.key_bits) w |= (uint64_t)key << lay.key_shift();
+  return w;
+}
+
 // The (time, sequence) part of row i's sort word, as a number: ordering by it is ordering by
 // (primary, seq NULLS FIRST).  Not for layouts with seq_wide.
 __device__ __forceinline__ uint64_t time_of(const Layout &lay, int64_t ts, bool seq_ok, int64_t seq) {
@@ -405,7 +416,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *
   int64_t end = begin + (int64_t)tiles_per_block * RS_TILE;
   if (end > n) end = n;
   int wave = threadIdx.x >> 6;
-  if (GEN && gen.vec4) {
+  if (GEN == 3) {
+    // the digit comes from the key column alone (a pass over key bits of rows whose words the
+    // scatter builds itself): 4 bytes per row are read and nothing is written
+    const int ks = gen.lay.key_shift();
+    for (int64_t i = begin + (int64_t)threadIdx.x * 4; i < end; i += (int64_t)RS_THREADS * 4) {
+      if (gen.vec4 && i + 4 <= end) {
+        const int4 kv = *reinterpret_cast<const int4 *>(gen.key + i);
+        const uint32_t kk[4] = {(uint32_t)kv.x, (uint32_t)kv.y, (uint32_t)kv.z, (uint32_t)kv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) atomicAdd(&hist[wave][(uint32_t)(((uint64_t)kk[u] << ks) >> shift) & mask], 1u);
+      } else {
+        for (int64_t r = i; r < end && r < i + 4; ++r)
+          atomicAdd(&hist[wave][(uint32_t)(((uint64_t)(uint32_t)gen.key[r] << ks) >> shift) & mask], 1u);
+      }
+    }
+  } else if (GEN && gen.vec4) {
     // four consecutive rows per thread, wide loads and stores (begin is a multiple of the tile)
     for (int64_t i = begin + (int64_t)threadIdx.x * 4; i < end; i += (int64_t)RS_THREADS * 4) {
       uint64_t w[4];
@@ -543,11 +569,14 @@ int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
 // it), so a pass moves one 8-byte stream instead of a word and an id.  1 = packed in and out
 // (every pass but the last), 2 = packed in, and out come the plain word and the row id, both
 // written from the one staged copy (the last pass).  0 = separate row ids.
-template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int PACK>
+// GENW: the sort words are not read but built here from the table's columns (first pass of rows
+// whose digit the histogram took from the key column): no pass writes or re-reads plain words.
+template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int PACK, bool GENW = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
-    PayPtrs pp, int id_bits, const int32_t *run_if) {
+    PayPtrs pp, int id_bits, const int32_t *run_if, GenArgs gen) {
+  static_assert(!GENW || (FIRST && PACK == 0 && NPAY <= 0), "words are built in the plain first pass only");
   // NPAY < 0: -NPAY columns that are already in the order of the rows being moved (read by
   // position, no dependent load: the larger plain tile serves, nothing is requested ahead)
   constexpr bool PAY = NPAY != 0;
@@ -627,7 +656,44 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
 #pragma unroll
       for (int it = 0; it < RS_ITEMS; ++it) {
         int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
-        k[it] = pos < tile_n ? kin[tile_base + pos] : 0ull;
+        if (!GENW) k[it] = pos < tile_n ? kin[tile_base + pos] : 0ull;
+      }
+      if (GENW) {
+        // every load first and none inside a per-row branch (a slot past the tile reads the tile's
+        // last row): a wave then has all its requests in flight at once
+        // (uniform base pointers and 32-bit offsets: one address register per load)
+        const int64_t *ts_t = gen.ts + tile_base;
+        const int32_t *key_t = gen.key + tile_base;
+        int64_t tsv[RS_ITEMS];
+        uint32_t kv[RS_ITEMS], mb[RS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+          const uint32_t pos = (uint32_t)(wave * (64 * RS_ITEMS) + it * 64 + lane);
+          const uint32_t at = pos < (uint32_t)tile_n ? pos : (uint32_t)tile_n - 1u;
+          tsv[it] = ts_t[at];
+          kv[it] = (uint32_t)key_t[at];
+          mb[it] = 0;
+        }
+        for (int m = 0; m < gen.n_masks; ++m) {
+          const uint8_t *mp = gen.masks.p[m];
+          if (mp) {
+            mp += tile_base;
+#pragma unroll
+            for (int it = 0; it < RS_ITEMS; ++it) {
+              const uint32_t pos = (uint32_t)(wave * (64 * RS_ITEMS) + it * 64 + lane);
+              const uint32_t at = pos < (uint32_t)tile_n ? pos : (uint32_t)tile_n - 1u;
+              mb[it] |= (mp[at] ? 1u : 0u) << m;
+            }
+          } else {
+#pragma unroll
+            for (int it = 0; it < RS_ITEMS; ++it) mb[it] |= 1u << m;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+          const int pos = wave * (64 * RS_ITEMS) + it * 64 + lane;
+          k[it] = pos < tile_n ? plain_word(gen.lay, tsv[it], kv[it], mb[it]) : 0ull;
+        }
       }
     }
     STICK();
@@ -1829,14 +1895,46 @@ template <int THREADS, int ITEMS, int NPAY, int BITS, int PACK>
 static void radix_scatter_launch(OrderBuffers &b, int64_t n, int cur, int shift, uint32_t mask, int nbits,
                                  hipStream_t st, const PayPtrs &pp, bool first, const SortGeom &g,
                                  int id_bits) {
+  GenArgs none;
+  memset(&none, 0, sizeof(none));
   if (first)
     hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, PACK>), dim3(g.grid), dim3(THREADS),
                        0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
-                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if);
+                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if, none);
   else
     hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, false, PACK>), dim3(g.grid), dim3(THREADS),
                        0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, shift, mask, nbits,
-                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if);
+                       g.tiles_per_block, b.counts, pp, id_bits, b.run_if, none);
+}
+
+// Whether a first pass may take its digits from the key column and build the words in the
+// scatter: the pass lies inside the key field of plain (not bucketed, not id-carrying) words.
+static bool genw_ok(const GenArgs *gen, int lo, int pack) {
+  return gen && gen->key && !gen->key_pack && gen->id_bits == 0 && pack == 0 && lo >= gen->lay.key_shift() &&
+         !(gen->lay.seq_bits && gen->seq) &&
+         !getenv("TEMPO_NO_FUSED_WORDS");
+}
+
+// The first pass of rows that are time-ordered already, over (part of) the key field: histogram of
+// the key column, then one sweep that builds the words, moves them, the row ids (= positions) and
+// the columns that travel with the rows (NPAY = 0 or -1).
+template <int THREADS, int ITEMS, int NPAY, int BITS>
+static void radix_first_pass_fused(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
+                                   const PayPtrs &pp, const GenArgs &gen) {
+  SortGeom g = sort_geom(n, THREADS * ITEMS);
+  const uint32_t mask = (1u << nbits) - 1;
+  {
+    ProfScope ps("radix_hist_kernel+keys", st);
+    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 3>), dim3(g.grid), dim3(THREADS), 0, st,
+                       (const uint64_t *)nullptr, n, lo, mask, g.tiles_per_block, b.counts, gen, (uint64_t *)nullptr, b.run_if);
+    TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid, b.run_if);
+  }
+  {
+    ProfScope ps(NPAY == 0 ? "radix_scatter_kernel+words" : "radix_scatter_kernel+words+carried", st);
+    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, 0, true>), dim3(g.grid), dim3(THREADS),
+                       0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                       g.tiles_per_block, b.counts, pp, 0, b.run_if, gen);
+  }
 }
 
 // One stable LSD pass (histogram, scan, scatter) over `nbits` bits at `lo`.  gen != nullptr: the
@@ -1881,6 +1979,10 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
 #define TEMPO_RS_ITEMS 12
 #endif
 constexpr int kPlainItems = TEMPO_RS_ITEMS;  // rows per thread of the passes that move pairs (and travelling columns) only
+#ifndef TEMPO_FUSED_ITEMS
+#define TEMPO_FUSED_ITEMS 8
+#endif
+constexpr int kFusedItems = TEMPO_FUSED_ITEMS;  // ... of a first pass that also builds the words (their inputs need registers)
 
 template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
@@ -1946,11 +2048,20 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
       memset(&pp, 0, sizeof(pp));
       pp.n = n_pay;
       for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
-      if (n_pay == 1)
+      if (p == 0 && genw_ok(g, lo, pack)) {
+        // the only pass: the row ids are the positions, so the payload is read where the rows are
+        // read (no dependent load), and the words are built on the way
+        pp.positional = 1;
+        if (nbits <= 8) radix_first_pass_fused<1024, kFusedItems, -1, 8>(b, n, cur, lo, nbits, st, pp, *g);
+        else radix_first_pass_fused<1024, kFusedItems, -1, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, *g);
+      } else if (n_pay == 1)
         radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       else
         radix_one_pass<1024, 4, kMaxPay>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
       if (carried) *carried = true;
+    } else if (p == 0 && genw_ok(g, lo, pack)) {
+      if (nbits <= 8) radix_first_pass_fused<1024, kFusedItems, 0, 8>(b, n, cur, lo, nbits, st, none, *g);
+      else radix_first_pass_fused<1024, kFusedItems, 0, RS_MAX_BITS>(b, n, cur, lo, nbits, st, none, *g);
     } else {
       radix_one_pass<1024, kPlainItems, 0>(b, n, cur, lo, nbits, st, none, g, false, pack, id_bits);
     }

@@ -61,3 +61,45 @@ def test_order_fuzz(orc, monkeypatch, shape, n, n_keys, with_seq, floor_seconds,
     sfield = np.zeros(n, np.int64) if seq is None else np.where(sv != 0, seq - seq.min() + 1, 0)
     want = np.lexsort((np.arange(n), sfield, prim, key))
     assert np.array_equal(perm.cpu().numpy().astype(np.int64), want)
+
+
+@pytest.mark.parametrize("n,n_keys,shape", [(5_000, 2, "time"), (70_001, 100, "time"), (1_200_000, 300, "time"),
+                                            (300_000, 200, "per_key"), (1_100_000, 9, "per_key"),
+                                            (8_193, 256, "time"), (16_384, 1, "time")])
+def test_time_ordered_first_pass_builds_its_words(orc, monkeypatch, n, n_keys, shape):
+    """A time-ordered (or per-key-ordered) feed takes one pass over the key bits whose scatter builds
+    the sort words itself from the key / time / validity columns: the order, the ordered metric and the
+    statistics are those of the pass that reads words laid out beforehand, and the oracle's."""
+    from tempo_amd import _lib, ops
+    rng = np.random.default_rng(n + n_keys)
+    key, ts = _table(rng, n, n_keys, shape, 250_000, 4 * n)
+    x = np.round(rng.normal(100, 3, n), 2)
+    xv = (rng.random(n) > 0.1).astype(np.uint8)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    runs = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("TEMPO_NO_FUSED_WORDS", raising=False)
+        else:
+            monkeypatch.setenv("TEMPO_NO_FUSED_WORDS", "1")
+        _lib.profile_enable(True)
+        _lib.profile_reset()
+        perm = ops.sort_order(d(key), d(ts), n_keys, floor_seconds=True)
+        st = ops.range_stats(d(key), d(ts), d(x), d(xv), n_keys, 30)
+        torch.cuda.synchronize()
+        names = {name for name, _, _ in _lib.profile_read()}
+        _lib.profile_enable(False)
+        if n_keys > 1 and (shape == "time" or n >= 1 << 20):  # the path under test really ran (or really did not)
+            assert fused == any("scatter_kernel+words" in name for name in names), names
+        runs[fused] = (perm.cpu().numpy(), {k: v.cpu().numpy() for k, v in st.items() if isinstance(v, torch.Tensor)})
+    assert np.array_equal(runs[True][0], runs[False][0])
+    assert np.array_equal(runs[True][0], np.lexsort((np.arange(n), ts // 1_000_000, key)))
+    for name, a in runs[True][1].items():
+        b = runs[False][1][name]
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), name
+    e = orc.range_stats(key, ts, x, xv, 30)
+    assert np.array_equal(runs[True][1]["perm"].astype(np.int64), e["perm"])
+    assert np.array_equal(runs[True][1]["count"], e["count"])
+    ok = e["stat_valid"].astype(bool)
+    assert np.array_equal(runs[True][1]["min"][ok], e["min"][ok])
+    np.testing.assert_allclose(runs[True][1]["mean"][ok], e["mean"][ok], rtol=1e-9)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--runs", type=int, default=8)
     ap.add_argument("--density", type=float, default=1.0, help="ticks per second and symbol (bench.py: 1)")
     ap.add_argument("--any-order", action="store_true", help="let the library return the rows in any order")
+    ap.add_argument("--orders", default="time_ordered,runs,permuted", help="which row orders to time")
     args = ap.parse_args()
     global ANY_ORDER
     ANY_ORDER = args.any_order
@@ -51,19 +52,22 @@ def main():
     n = args.rows
     tk = bench.gen_ticks(dev, n, 100, 2345, shards=1.0 / args.density)
     out = {}
-    out["time_ordered"] = timed(tk)
+    orders = args.orders.split(",")
+    if "time_ordered" in orders:
+        out["time_ordered"] = timed(tk)
     # N runs: rank r of N keeps every N-th block of 1/N of the rows... simplest faithful stand-in:
     # split the feed into N interleaved sub-feeds (row i goes to run i mod N) and lay them back to back
     idx = torch.arange(n, device=dev).view(-1, args.runs).t().reshape(-1) if n % args.runs == 0 else None
-    if idx is not None:
+    if idx is not None and "runs" in orders:
         runs = {k: v[idx] for k, v in tk.items()}
         del idx
         out["runs_%d" % args.runs] = timed(runs)
         del runs
-    p = torch.randperm(n, device=dev)
-    perm = {k: v[p] for k, v in tk.items()}
-    del p
-    out["permuted"] = timed(perm)
+    if "permuted" in orders:
+        p = torch.randperm(n, device=dev)
+        perm = {k: v[p] for k, v in tk.items()}
+        del p
+        out["permuted"] = timed(perm)
     print(json.dumps(out))
 
 
