@@ -2016,7 +2016,7 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
   // stream, and the last pass hands out plain words and row ids again.  Only when the words are
   // laid out here (gen), so that nobody else ever sees the packed form.
   const int id_bits = bits_for((uint64_t)(n > 1 ? n - 1 : 1));
-  const bool packed = gen != nullptr && passes > 1 && hi_bit + id_bits <= 64;
+  const bool packed = gen != nullptr && passes > 1 && hi_bit + id_bits <= 64 && !carry_buf;
   GenArgs gen_packed;
   if (packed) {
     gen_packed = *gen;
@@ -2037,9 +2037,15 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
       pp.positional = 1;
       for (int c = 0; c < n_pay; ++c) {
         pp.src[c] = p == 0 ? pay_src[c] : carry_buf[2 * c + ((p - 1) & 1)];
-        pp.out[c] = carry_buf[2 * c + (p & 1)];
+        // the last pass delivers the column where the caller wants it, if the caller says where
+        pp.out[c] = (last && pay_out) ? pay_out[c] : carry_buf[2 * c + (p & 1)];
       }
-      radix_one_pass<1024, kPlainItems, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
+      if (p == 0 && genw_ok(g, lo, pack)) {
+        if (nbits <= 8) radix_first_pass_fused<1024, kFusedItems, -1, 8>(b, n, cur, lo, nbits, st, pp, *g);
+        else radix_first_pass_fused<1024, kFusedItems, -1, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, *g);
+      } else {
+        radix_one_pass<1024, kPlainItems, -1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
+      }
       if (carry_at) *carry_at = p & 1;
     } else if (last && n_pay > 0) {
       // the last pass also fetches the payload through the row ids: one column with six rows per
@@ -2212,8 +2218,19 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
     return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, nullptr, nullptr, nullptr, at);
   }
   BucketGeom bg;
-  if (!bucketed_wanted(s, lay, sorted, b, &bg))
+  if (!bucketed_wanted(s, lay, sorted, b, &bg)) {
+    // a time-ordered feed whose key field takes more than one pass: the travelling columns move with
+    // the rows through every pass (buffers planned for it) instead of being fetched through the row
+    // ids at the end -- streams in place of a gather over the whole column
+    if (sorted == 2 && n_pay >= 1 && n_pay <= b.carry_cols && pay_out && passes_for(hi_bit - lo_bit) > 1 &&
+        !getenv("TEMPO_NO_CARRY_TIME")) {
+      int at = 0;
+      TMP_TRY(radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, nullptr, &gen, b.carry, &at));
+      if (carried) *carried = true;
+      return TMP_OK;
+    }
     return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
+  }
 
   // ---- bucket map: sampled rows per key -> buckets per key -> first bucket per key -> key per bucket
   const uint32_t nk = (uint32_t)plan_keys(s.key, s.n_keys);
