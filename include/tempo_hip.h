@@ -155,12 +155,12 @@ typedef struct {
   int32_t *left_in_place;
 } tmp_asof_args;
 
-/* Streams: every kernel runs on `stream`.  With TEMPO_JOIN_STREAMS=1 in the environment and both
- * sides at 2^20 rows or more, the right side is ordered on a stream of the library's own (one
- * per device, created on the first such call and kept), forked from and joined back into
- * `stream` by events inside the call -- everything the call enqueues is complete once `stream`
- * reaches what is enqueued after it, as for a single-stream call.  Calls that overlap on one
- * device share that stream and take turns on it. */
+/* Streams: every kernel runs on `stream`, with one exception: when both sides of a join have 2^20
+ * rows or more (and TEMPO_JOIN_STREAMS=0 is not in the environment), the right side is ordered on
+ * a stream of the library's own (one per device, created on the first such call and kept), forked
+ * from and joined back into `stream` by events inside the call -- everything the call enqueues is
+ * complete once `stream` reaches what is enqueued after it, as for a single-stream call.  Calls
+ * that overlap on one device share that stream and take turns on it. */
 size_t tmp_asof_join_workspace_bytes(const tmp_asof_args *a);
 int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -713,10 +713,11 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
   // the two extra event waits cost more than the overlap gives)
   hipStream_t rst = st;
   SideStream *side = nullptr;
-  // Opt-in (TEMPO_JOIN_STREAMS=1): 5x10^8 + 5x10^8 random-order rows join in 66.5 ms instead of 68.8;
-  // the kernels of the two sides then stretch each other, so per-kernel timings stop adding up.
+  // 5x10^8 + 5x10^8 random-order rows join in 61.8 ms instead of 64.1.  The kernels of the two sides
+  // then stretch each other, so per-kernel timings stop adding up: TEMPO_JOIN_STREAMS=0 keeps
+  // everything on the caller's stream (profiling runs that want durations which add up).
   const char *two = getenv("TEMPO_JOIN_STREAMS");
-  if (two && two[0] == '1' && a->n_right >= (1 << 20) && a->n_left >= (1 << 20)) side = side_stream();
+  if (!(two && two[0] == '0') && a->n_right >= (1 << 20) && a->n_left >= (1 << 20)) side = side_stream();
   if (side) side->busy.lock();
   SideJoin side_join(side, st);  // from here on every way out joins the side stream and releases it
   if (side) {

@@ -332,9 +332,10 @@ def test_asof_fused_table_ordered_feeds(orc, ops, order):
 
 
 def test_asof_right_side_on_its_own_stream(orc, ops, monkeypatch):
-    """TEMPO_JOIN_STREAMS=1 orders the right side on the library's own stream, forked from and joined
-    back into the caller's: the joined table is the oracle's, twice in a row (the stream and its
-    events are reused), and equal to what the single-stream call returns."""
+    """Sides of 2^20 rows or more: the right side is ordered on the library's own stream, forked from
+    and joined back into the caller's (TEMPO_JOIN_STREAMS=0 keeps everything on the caller's): the
+    joined table is the oracle's, twice in a row (the stream and its events are reused), and equal to
+    what the single-stream call returns."""
     rng = np.random.default_rng(67)
     nk, n = 40, 1_200_000
     key_l = rng.integers(0, nk, n).astype(np.int32)
@@ -349,9 +350,9 @@ def test_asof_right_side_on_its_own_stream(orc, ops, monkeypatch):
                                    [_dev(ts_r), _dev(bid), _dev(ask)], [None, _dev(mask), None],
                                    skip_nulls=True, ts_partition_val=10, fraction=0.1)
 
-    monkeypatch.delenv("TEMPO_JOIN_STREAMS", raising=False)
+    monkeypatch.setenv("TEMPO_JOIN_STREAMS", "0")
     one = run()
-    monkeypatch.setenv("TEMPO_JOIN_STREAMS", "1")
+    monkeypatch.delenv("TEMPO_JOIN_STREAMS", raising=False)
     idx, _ = orc.asof_join(key_l, ts_l, key_r, ts_r, valid_r=[None, mask], skip_nulls=True,
                            ts_partition_val=10, fraction=0.1)
     for _ in range(2):
