@@ -119,13 +119,17 @@ __device__ __forceinline__ void slot_add_f64(double v, double pivot, double &sd,
   bool okv = v == v;
   double d = okv ? v - pivot : 0.0;
   sd += d;
-  sq += d * d;
+  sq = __builtin_fma(d, d, sq);
   dc += okv ? 1u : 0u;
   mn = MinMax<double>::mn(mn, v);
   mx = MinMax<double>::mx(mx, v);
 }
 
-__device__ __forceinline__ constexpr int xi(int e) { return e + e / RK_SB; }
+// (slot numbers are never negative: the unsigned division is one shift)
+__device__ __forceinline__ constexpr int xi(int e) { return e + (int)((unsigned)e / (unsigned)RK_SB); }
+// The spare element after the first sub-block holds a NULL for good: the place a walk reads for the
+// slots beyond its end.
+constexpr int RK_NULL_AT = RK_SB;
 
 template <typename T>
 struct RsShared {
@@ -134,7 +138,7 @@ struct RsShared {
   // metric; for double a NULL slot holds NaN.  Slot e lives at xi(e): one spare element after every
   // sub-block, so that the threads that each add up one sub-block (lane stride = a sub-block) read
   // from distinct banks -- with the sub-blocks back to back sixteen lanes share a bank
-  T x[RK_CAP + RK_NSB];
+  T x[RK_CAP + RK_NSB + RK_SB / 2];  // (+ the reach of a walk's reads past the last slot)
   double bs[RK_NSB + 1];     // exclusive prefix over sub-blocks of sum(x - pivot)
   double bq[RK_NSB + 1];     // ... of sum((x - pivot)^2)
   uint64_t bi[kIntT ? RK_NSB + 1 : 1];  // ... of the exact integer sum (int64 metrics)
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   const int64_t re = t0 + RK_ROWS + RK_FWD < n ? t0 + RK_ROWS + RK_FWD : n;
   const int len = (int)(re - rs);
   const uint64_t base = comp[rs] >> low;
-  if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; }
+  if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; s.x[RK_NULL_AT] = MinMax<T>::null_slot(); }
   __syncthreads();
 #ifdef RK_TIMING
   long long tk[12]; int ntk = 0;
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
     const int e = r * RK_THREADS + tid;
-    const int64_t at = rs + (e < len ? e : len - 1);
-    wd[r] = comp[at];
-    xv[r] = xs[at];
+    const uint32_t at = (uint32_t)(e < len ? e : len - 1);  // (block-uniform base + 32-bit offset: one address register)
+    wd[r] = (comp + rs)[at];
+    xv[r] = (xs + rs)[at];
   }
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       const bool finj = okj && Ord<T>::finite(v);
       const double d = finj ? (double)v - pivot : 0.0;
       sd += d;
-      sq += d * d;
+      sq = __builtin_fma(d, d, sq);
       sc += (okj ? 1u : 0u) | ((okj && !finj) ? 0x10000u : 0u);
       vmn = MinMax<T>::mn(vmn, okj ? v : MinMax<T>::min_identity());
       vmx = MinMax<T>::mx(vmx, okj ? v : MinMax<T>::max_identity());
@@ -428,13 +432,13 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   uint32_t dc = 0;
   uint64_t isum = 0;
   T mn = MinMax<T>::min_identity(), mx = MinMax<T>::max_identity();
-  const int sa = a / RK_SB, sb = b / RK_SB;
+  const int sa = (int)((unsigned)a / (unsigned)RK_SB), sb = (int)((unsigned)b / (unsigned)RK_SB);  // 0 <= a <= b
   if (!slow) {
     // first and last sub-block: slot by slot up to the middle or the end of the sub-block,
     // whichever comes first; the half beyond the middle comes from the half aggregates
     constexpr int kHalf = RK_SB / 2;
-    const bool head_half = sa != sb && (a % RK_SB) < kHalf;   // head stops at the middle, + second half
-    const bool tail_half = sa != sb && (b % RK_SB) >= kHalf;  // first half + tail from the middle on
+    const bool head_half = sa != sb && (a & (RK_SB - 1)) < kHalf;   // head stops at the middle, + second half
+    const bool tail_half = sa != sb && (b & (RK_SB - 1)) >= kHalf;  // first half + tail from the middle on
     // both walks are at most half a sub-block long: a frame inside one sub-block is cut after its
     // first four slots
     const int head_end = sa == sb ? (b < a + kHalf - 1 ? b : a + kHalf - 1)
@@ -445,19 +449,26 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
         // every staged value is finite and NULL slots hold NaN: no per-slot tests needed.  All
         // eight slots are read at once (one beyond a walk reads as NULL and adds nothing) instead
         // of one LDS round trip per step of two loops whose lengths differ from lane to lane.
+        // A walk stays inside one sub-block, so its slots lie side by side in the padded array; a
+        // slot beyond the walk's end is read from the element that always holds a NULL.
+        // A walk stays inside one sub-block, so its slots lie side by side in the padded array: four
+        // reads off one address each.  What lies beyond the walk's end is turned into a NULL by
+        // replacing its upper half with a NaN's (one select per slot).
+        const double *ph = &s.x[xi(a)], *pt = &s.x[xi(tail_begin < RK_CAP ? tail_begin : RK_CAP - 1)];
+        const int nh = head_end - a + 1, nt = b - tail_begin + 1;  // slots in the walks (0 .. kHalf)
         double hv[kHalf], tv[kHalf];
 #pragma unroll
+        for (int u = 0; u < kHalf; ++u) { hv[u] = ph[u]; tv[u] = pt[u]; }
+        constexpr int kNanHi = 0x7ff80000;
+#pragma unroll
         for (int u = 0; u < kHalf; ++u) {
-          const int eh = a + u, et = tail_begin + u;
-          hv[u] = s.x[xi(eh < RK_CAP ? eh : RK_CAP - 1)];
-          tv[u] = s.x[xi(et < RK_CAP ? et : RK_CAP - 1)];
+          hv[u] = __hiloint2double(u < nh ? __double2hiint(hv[u]) : kNanHi, __double2loint(hv[u]));
+          tv[u] = __hiloint2double(u < nt ? __double2hiint(tv[u]) : kNanHi, __double2loint(tv[u]));
         }
 #pragma unroll
-        for (int u = 0; u < kHalf; ++u)
-          slot_add_f64(a + u <= head_end ? hv[u] : MinMax<double>::null_slot(), pivot, sd, sq, dc, mn, mx);
+        for (int u = 0; u < kHalf; ++u) slot_add_f64(hv[u], pivot, sd, sq, dc, mn, mx);
 #pragma unroll
-        for (int u = 0; u < kHalf; ++u)
-          slot_add_f64(tail_begin + u <= b ? tv[u] : MinMax<double>::null_slot(), pivot, sd, sq, dc, mn, mx);
+        for (int u = 0; u < kHalf; ++u) slot_add_f64(tv[u], pivot, sd, sq, dc, mn, mx);
       }
     }
     if (kInt || s.nonfinite) {
@@ -565,15 +576,16 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   // rs_store's arithmetic, with the reciprocal form of the zscore division
   {
     const bool okk = cnt > 0, sd_ok = cnt > 1;
-    o.count[i] = cnt;
-    o.mean[i] = okk ? mean : 0.0;
-    o.mn[i] = okk ? mn : (T)0;
-    o.mx[i] = okk ? mx : (T)0;
-    o.sum[i] = okk ? sum : (T)0;
-    o.stddev[i] = sd_ok ? stddev : 0.0;
+    const uint32_t ti = (uint32_t)tid;  // the tile's first row is block-uniform: one offset register serves all columns
+    (o.count + t0)[ti] = cnt;
+    (o.mean + t0)[ti] = okk ? mean : 0.0;
+    (o.mn + t0)[ti] = okk ? mn : (T)0;
+    (o.mx + t0)[ti] = okk ? mx : (T)0;
+    (o.sum + t0)[ti] = okk ? sum : (T)0;
+    (o.stddev + t0)[ti] = sd_ok ? stddev : 0.0;
     const bool z_ok = (cki & 1u) && sd_ok && stddev != 0.0;  // Spark Divide: NULL on a zero divisor
-    o.zscore[i] = z_ok ? ((double)s.x[xi(li)] - mean) * fast_rcp(stddev) : 0.0;
-    o.valid[i] = (uint8_t)((okk ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
+    (o.zscore + t0)[ti] = z_ok ? ((double)s.x[xi(li)] - mean) * fast_rcp(stddev) : 0.0;
+    (o.valid + t0)[ti] = (uint8_t)((okk ? 1 : 0) | (sd_ok ? 2 : 0) | (z_ok ? 4 : 0));
   }
 #ifdef RK_TIMING
   RTICK();
