@@ -227,8 +227,12 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       s.ck[e] = c;
       s.x[xi(e)] = xv[r];
       // pivot = first finite value of the region: one LDS atomic per wave, not per slot
+      // (and only where it would lower the value: after the first wave's that is almost never)
       uint64_t bal = __ballot(fin[r]);
-      if (bal && lane == 0) atomicMin(&s.pivot_at, e + (int)__ffsll((long long)bal) - 1);
+      if (bal && lane == 0) {
+        const int cand = e + (int)__ffsll((long long)bal) - 1;
+        if (cand < __hip_atomic_load(&s.pivot_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMin(&s.pivot_at, cand);
+      }
     }
   }
   __syncthreads();
@@ -270,28 +274,44 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     uint32_t sc1 = 0;
     uint64_t si1 = 0;
     T vmn1 = vmn, vmx1 = vmx;
-    uint32_t cs[RK_SB];
+    bool plain = false;  // a double metric without NaN / inf in the region: a slot is NULL exactly when it holds NaN
+    if constexpr (!kInt) plain = s.nonfinite == 0;
+    if (plain) {
+      if constexpr (!kInt) {
 #pragma unroll
-    for (int q4 = 0; q4 < RK_SB / 4; ++q4) {
-      const uint4 c4 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB + 4 * q4]);
-      cs[4 * q4] = c4.x; cs[4 * q4 + 1] = c4.y; cs[4 * q4 + 2] = c4.z; cs[4 * q4 + 3] = c4.w;
-    }
+        for (int j = 0; j < RK_SB; ++j) {
+          slot_add_f64(s.x[b * (RK_SB + 1) + j], pivot, sd, sq, sc, vmn, vmx);
+          if (j == RK_SB / 2 - 1) {  // the first half is complete: keep it and start the second
+            sd1 = sd; sq1 = sq; sc1 = sc; vmn1 = vmn; vmx1 = vmx;
+            sd = 0.0; sq = 0.0; sc = 0;
+            vmn = MinMax<T>::min_identity(); vmx = MinMax<T>::max_identity();
+          }
+        }
+      }
+    } else {
+      uint32_t cs[RK_SB];
 #pragma unroll
-    for (int j = 0; j < RK_SB; ++j) {
-      const T v = s.x[b * (RK_SB + 1) + j];
-      const bool okj = (cs[j] & 1u) != 0;
-      const bool finj = okj && Ord<T>::finite(v);
-      const double d = finj ? (double)v - pivot : 0.0;
-      sd += d;
-      sq = __builtin_fma(d, d, sq);
-      sc += (okj ? 1u : 0u) | ((okj && !finj) ? 0x10000u : 0u);
-      vmn = MinMax<T>::mn(vmn, okj ? v : MinMax<T>::min_identity());
-      vmx = MinMax<T>::mx(vmx, okj ? v : MinMax<T>::max_identity());
-      if (kInt) si += okj ? (uint64_t)v : 0ull;
-      if (j == RK_SB / 2 - 1) {  // the first half is complete: keep it and start the second
-        sd1 = sd; sq1 = sq; sc1 = sc; si1 = si; vmn1 = vmn; vmx1 = vmx;
-        sd = 0.0; sq = 0.0; sc = 0; si = 0;
-        vmn = MinMax<T>::min_identity(); vmx = MinMax<T>::max_identity();
+      for (int q4 = 0; q4 < RK_SB / 4; ++q4) {
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(&s.ck[b * RK_SB + 4 * q4]);
+        cs[4 * q4] = c4.x; cs[4 * q4 + 1] = c4.y; cs[4 * q4 + 2] = c4.z; cs[4 * q4 + 3] = c4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < RK_SB; ++j) {
+        const T v = s.x[b * (RK_SB + 1) + j];
+        const bool okj = (cs[j] & 1u) != 0;
+        const bool finj = okj && Ord<T>::finite(v);
+        const double d = finj ? (double)v - pivot : 0.0;
+        sd += d;
+        sq = __builtin_fma(d, d, sq);
+        sc += (okj ? 1u : 0u) | ((okj && !finj) ? 0x10000u : 0u);
+        vmn = MinMax<T>::mn(vmn, okj ? v : MinMax<T>::min_identity());
+        vmx = MinMax<T>::mx(vmx, okj ? v : MinMax<T>::max_identity());
+        if (kInt) si += okj ? (uint64_t)v : 0ull;
+        if (j == RK_SB / 2 - 1) {  // the first half is complete: keep it and start the second
+          sd1 = sd; sq1 = sq; sc1 = sc; si1 = si; vmn1 = vmn; vmx1 = vmx;
+          sd = 0.0; sq = 0.0; sc = 0; si = 0;
+          vmn = MinMax<T>::min_identity(); vmx = MinMax<T>::max_identity();
+        }
       }
     }
     s.hs2[b] = sd; s.hq2[b] = sq; s.hc2[b] = sc;
