@@ -242,13 +242,25 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
 
   // first slot at or after the frame start of the row whose relative sort word is krel, searched
   // in slots [lo, hi]; the row's full word is base + krel (rows with a saturated krel are deferred)
+  // Rows of the key the region starts in (all rows of most tiles) have their time field at
+  // base's + krel, so the frame starts w before the row or at the region's first slot: 32-bit
+  // arithmetic.  same_key = the largest krel of that key; rows of later keys take the general form.
+  const uint64_t room = pmask - (base & pmask);
+  const uint32_t same_key = (uint32_t)(room < RK_SAT ? room : RK_SAT);
+  const uint32_t w32 = (uint32_t)(w < RK_SAT ? w : RK_SAT);
   auto frame_first = [&](uint32_t krel, int lo, int hi) {
-    const uint64_t kstart = frame_start_key(base + krel, pmask, w);
-    const uint64_t srel64 = kstart > base ? kstart - base : 0;
-    const uint32_t srel = (uint32_t)(srel64 < RK_SAT ? srel64 : RK_SAT);
+    uint32_t srel;
+    if (krel <= same_key) {
+      srel = krel > w32 ? krel - w32 : 0u;
+    } else {
+      const uint64_t kstart = frame_start_key(base + krel, pmask, w);
+      const uint64_t srel64 = kstart > base ? kstart - base : 0;
+      srel = (uint32_t)(srel64 < RK_SAT ? srel64 : RK_SAT);
+    }
+    const uint32_t bound = srel << 1;  // staged words carry the validity bit below the relative word
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if ((s.ck[mid] >> 1) < srel) lo = mid + 1;
+      if (s.ck[mid] < bound) lo = mid + 1;
       else hi = mid;
     }
     return lo;
@@ -432,11 +444,12 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     int step = 1;
     int lo = li + 1;
     hi = li + 1;
-    while (hi < len && (s.ck[hi] >> 1) <= krel) { lo = hi + 1; hi += step; step <<= 1; }
+    const uint32_t peer_max = cki | 1u;  // the largest staged word of the row's own second
+    while (hi < len && s.ck[hi] <= peer_max) { lo = hi + 1; hi += step; step <<= 1; }
     if (hi > len) hi = len;
     while (lo < hi) {
       int mid = (lo + hi) >> 1;
-      if ((s.ck[mid] >> 1) <= krel) lo = mid + 1;
+      if (s.ck[mid] <= peer_max) lo = mid + 1;
       else hi = mid;
     }
     b = lo - 1;
