@@ -218,7 +218,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       if (e < len) {
         const uint64_t word = wd[r];
         uint64_t rel = (word >> low) - base;
-        ok[r] = ((word >> o.vbit) & 1ull) != 0;
+        ok[r] = (((uint32_t)word >> o.vbit) & 1u) != 0;  // (the validity bits are the word's lowest)
         c = (uint32_t)(rel < RK_SAT ? rel : RK_SAT) << 1 | (ok[r] ? 1u : 0u);
         fin[r] = ok[r] && Ord<T>::finite(xv[r]);
         if (ok[r] && !fin[r]) s.nonfinite = 1;
