@@ -22,6 +22,6 @@ W=$(ls -t $O/write/*/*counter_collection.csv | head -1)
 python3 profiles/summarize_pmc.py $S $F $W $O/${TAG}_bench1b_pmc_traffic.json > $O/summary.txt
 cp $S $O/${TAG}_bench1b_kernel_stats.csv
 cp $(ls -t $O/trace1/*/*kernel_stats.csv | head -1) $O/${TAG}_bench1b_kernel_stats_one_stream.csv
-tail -1 $O/trace1.log > $O/${TAG}_bench1b_traced_one_stream.json
-tail -1 $O/trace.log > $O/${TAG}_bench1b_traced.json
+grep "^{\"metric\"" $O/trace1.log | tail -1 > $O/${TAG}_bench1b_traced_one_stream.json
+grep "^{\"metric\"" $O/trace.log | tail -1 > $O/${TAG}_bench1b_traced.json
 head -30 $O/summary.txt
