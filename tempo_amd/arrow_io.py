@@ -13,6 +13,9 @@ bitmap as the NULL mask.
                                 device join: the joined table in (key, ts) order
   range_stats(table, ...)       TSDF.withRangeStats (python/tempo/tsdf.py:673-721)
 """
+import concurrent.futures
+import os
+
 import numpy as np
 import pyarrow as pa
 import pyarrow.compute as pc
@@ -28,6 +31,61 @@ def _combined(arr):
     return arr
 
 
+# Dictionary-encoding a string column and materialising one from dictionary codes are the two
+# host-side passes that scale with the row count; Arrow runs each on one thread and releases the
+# GIL meanwhile, so long columns are cut into slices that a few threads take side by side.
+HOST_THREADS = max(1, int(os.environ.get("TEMPO_HOST_THREADS", "8")))
+PARALLEL_MIN_ROWS = 1 << 18
+_POOL = None
+
+
+def _slices(n):
+    """[(start, length)] of up to HOST_THREADS slices of n rows; one slice for short columns."""
+    if n < PARALLEL_MIN_ROWS or HOST_THREADS == 1:
+        return [(0, n)]
+    step = -(-n // HOST_THREADS)
+    return [(at, min(step, n - at)) for at in range(0, n, step)]
+
+
+def _map(fn, items):
+    global _POOL
+    if len(items) <= 1:
+        return [fn(x) for x in items]
+    if _POOL is None:
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=HOST_THREADS, thread_name_prefix="tempo-host")
+    return list(_POOL.map(fn, items))
+
+
+def dictionary_encode(arr, null_encoding="mask"):
+    """pc.dictionary_encode(arr, null_encoding) as (dictionary, int32 indices): same dictionary (values
+    in order of first appearance) and same indices, the indices as a ChunkedArray when the column was
+    long enough to be encoded slice by slice."""
+    arr = _combined(arr)
+    parts = _slices(len(arr))
+    if len(parts) == 1:
+        enc = pc.dictionary_encode(arr, null_encoding=null_encoding)
+        return enc.dictionary, enc.indices
+    encs = _map(lambda sl: pc.dictionary_encode(arr.slice(*sl), null_encoding=null_encoding), parts)
+    # values in order of first appearance over the slices in order = over the whole column
+    dictionary = pc.unique(pa.concat_arrays([e.dictionary for e in encs]))
+
+    def remap(e):
+        to_global = pc.index_in(e.dictionary, value_set=dictionary).cast(pa.int32())
+        return to_global.take(e.indices)   # NULL indices (null_encoding="mask") stay NULL
+    return dictionary, pa.chunked_array(_map(remap, encs), type=pa.int32())
+
+
+def dictionary_take(dictionary, indices):
+    """dictionary.take(indices) -- the column a dictionary and its codes stand for -- as an Array, or
+    as a ChunkedArray built slice by slice on several threads when it is long."""
+    parts = _slices(len(indices))
+    if len(parts) == 1:
+        return dictionary.take(indices)
+    taken = _map(lambda sl: dictionary.take(indices.slice(*sl)), parts)
+    chunks = [c for t in taken for c in (t.chunks if isinstance(t, pa.ChunkedArray) else [t])]
+    return pa.chunked_array(chunks, type=dictionary.type)
+
+
 def encode_keys(tables, cols):
     """Dictionary-encode the partition columns of several tables with one shared dictionary.
     Returns ([int32 numpy codes per table], n_keys, decode) where decode(codes) -> list of
@@ -38,16 +96,16 @@ def encode_keys(tables, cols):
     dense, dicts, col_codes = None, [], []
     for c in cols:
         whole = pa.concat_arrays([_combined(t[c]) for t in tables])
-        enc = pc.dictionary_encode(whole, null_encoding="encode")
-        codes = enc.indices.to_numpy(zero_copy_only=False).astype(np.int64)
-        dicts.append(enc.dictionary)
+        dictionary, indices = dictionary_encode(whole, null_encoding="encode")
+        codes = _combined(indices).to_numpy(zero_copy_only=False).astype(np.int64)
+        dicts.append(dictionary)
         col_codes.append(codes)
         if dense is None:
             dense = codes
         else:
             # re-densified after every column: the running code stays below the row count, so
             # (rows x cardinality) cannot wrap int64 however many columns there are
-            _, dense = np.unique(dense * max(len(enc.dictionary), 1) + codes, return_inverse=True)
+            _, dense = np.unique(dense * max(len(dictionary), 1) + codes, return_inverse=True)
             dense = dense.astype(np.int64)
     if len(cols) > 1:
         n_keys = int(dense.max()) + 1 if len(dense) else 1
@@ -62,9 +120,9 @@ def encode_keys(tables, cols):
     def decode(codes):
         codes = np.asarray(codes, dtype=np.int64)
         if first_row is None:
-            return [dicts[0].take(pa.array(codes, type=pa.int64()))]
+            return [dictionary_take(dicts[0], pa.array(codes, type=pa.int64()))]
         rows = first_row[codes]
-        return [dicts[j].take(pa.array(col_codes[j][rows], type=pa.int64())) for j in range(len(cols))]
+        return [dictionary_take(dicts[j], pa.array(col_codes[j][rows], type=pa.int64())) for j in range(len(cols))]
 
     parts, at = [], 0
     for n in lens:
@@ -80,15 +138,14 @@ def encode_keys_dev(tables, cols):
         parts, n_keys, decode = encode_keys(tables, cols)
         return [None if p is None else col.to_dev(p) for p in parts], n_keys, decode
     whole = pa.concat_arrays([_combined(t[cols[0]]) for t in tables])
-    enc = pc.dictionary_encode(whole, null_encoding="encode")
-    dictionary, indices = enc.dictionary, enc.indices
+    dictionary, indices = dictionary_encode(whole, null_encoding="encode")
     n_keys = max(len(dictionary), 1)
     codes, _, _ = ops.arrow_import(indices, "i32")
     parts, at = [], 0
     for t in tables:
         parts.append(codes[at:at + t.num_rows])
         at += t.num_rows
-    return parts, n_keys, (lambda c: [dictionary.take(pa.array(np.asarray(c, dtype=np.int64), type=pa.int64()))])
+    return parts, n_keys, (lambda c: [dictionary_take(dictionary, pa.array(np.asarray(c, dtype=np.int64), type=pa.int64()))])
 
 
 def timestamps_dev(arr):
@@ -133,10 +190,9 @@ def payload_to_device(arr):
         vals, valid, _ = ops.arrow_import(arr, "i64_raw")
         dec = lambda v, ok: _masked(v, pa.int64(), ok).cast(t)
     else:
-        enc = pc.dictionary_encode(_combined(arr))
-        vals, valid, _ = ops.arrow_import(enc.indices, "i64")
-        dictionary = enc.dictionary
-        dec = lambda v, ok: dictionary.take(_masked(v, pa.int64(), ok))
+        dictionary, indices = dictionary_encode(arr)
+        vals, valid, _ = ops.arrow_import(indices, "i64")
+        dec = lambda v, ok: dictionary_take(dictionary, _masked(v, pa.int64(), ok))
     return vals, valid, dec
 
 
@@ -213,7 +269,7 @@ def permute_table(table, perm, key=None):
         else:
             if perm_host is None:
                 perm_host = pa.array(to_host([perm])[0])
-            arrays.append(arr.take(perm_host))
+            arrays.append(dictionary_take(arr, perm_host))
     flat = [key_codes] if key_codes is not None else []
     for _, moved, mvalid, _ in pending:
         flat.append(moved)

@@ -73,3 +73,40 @@ def test_arrow_import_refuses_values_that_would_wrap():
     with pytest.raises(OverflowError):
         ops.arrow_import(pa.chunked_array([pa.array([1, None], type=pa.timestamp("ms")),
                                            pa.array([-9_223_372_036_854_776], type=pa.timestamp("ms"))]), "i64")
+
+
+def test_threaded_dictionary_passes_equal_arrows_own(monkeypatch):
+    """Long columns are dictionary-encoded and rebuilt from their codes slice by slice on several
+    threads: dictionary, indices and the rebuilt column are those of one pyarrow call over the whole
+    column -- NULL keys as a dictionary entry of their own or as NULL indices, slices without some of
+    the values, a key that first appears in a late slice."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    from tempo_amd import arrow_io
+    monkeypatch.setattr(arrow_io, "PARALLEL_MIN_ROWS", 1000)
+    monkeypatch.setattr(arrow_io, "HOST_THREADS", 5)
+    rng = np.random.default_rng(5)
+    n = 12_345
+    values = np.array(["k%02d" % i for i in range(40)] + [None], dtype=object)
+    picks = rng.integers(0, 41, n)
+    picks[: n // 2] = np.minimum(picks[: n // 2], 20)    # the upper keys appear in the later slices only
+    picks[-7] = 39
+    arr = pa.array(values[picks], type=pa.string())
+    for mode in ("encode", "mask"):
+        dictionary, indices = arrow_io.dictionary_encode(arr, null_encoding=mode)
+        assert isinstance(indices, pa.ChunkedArray) and indices.num_chunks == 5
+        want = pc.dictionary_encode(arr, null_encoding=mode)
+        assert dictionary.equals(want.dictionary)
+        assert indices.combine_chunks().equals(want.indices)
+        back = arrow_io.dictionary_take(dictionary, indices.combine_chunks())
+        assert isinstance(back, pa.ChunkedArray) and back.combine_chunks().equals(arr)
+    # chunked input, and a take of a chunked column
+    chunked = pa.chunked_array([arr.slice(0, 5000), arr.slice(5000)])
+    dictionary, indices = arrow_io.dictionary_encode(chunked, null_encoding="encode")
+    assert dictionary.equals(pc.dictionary_encode(arr, null_encoding="encode").dictionary)
+    perm = pa.array(rng.permutation(n))
+    assert arrow_io.dictionary_take(chunked, perm).combine_chunks().equals(arr.take(perm))
+    # short columns: one call, plain arrays
+    d, i = arrow_io.dictionary_encode(arr.slice(0, 500))
+    assert isinstance(i, pa.Array) and isinstance(arrow_io.dictionary_take(d, i), pa.Array)
