@@ -20,10 +20,11 @@
 namespace tmp {
 
 constexpr int RK_ROWS = 1024;
-#ifndef TEMPO_RK_CAP
-#define TEMPO_RK_CAP 2560
-#endif
-constexpr int RK_CAP = TEMPO_RK_CAP;
+// Slots of the staged region: the kernel comes in three sizes, chosen per call from how many rows a
+// frame is expected to hold (rs_region_cap) -- everything a block does before its rows' own work
+// (staging, sub-block sums, scans) grows with the region, a frame that leaves it sends the column
+// down the wide path.
+constexpr int RK_CAP_MAX = 2560;
 constexpr int RK_THREADS = 1024;
 constexpr int RK_FWD = 256;  // rows staged after the tile
 #ifndef TEMPO_RK_WPS
@@ -34,13 +35,17 @@ constexpr int RK_WAVES_PER_SIMD = TEMPO_RK_WPS;  // 8 = two 1024-thread blocks p
 #define TEMPO_RK_SB 8
 #endif
 constexpr int RK_SB = TEMPO_RK_SB;      // slots per sub-block (4 or 8)
-constexpr int RK_NSB = RK_CAP / RK_SB;  // 640
 constexpr int RK_GRP = 16;              // sub-blocks per group (one DPP row of lanes)
-constexpr int RK_NGRP = RK_NSB / RK_GRP;  // 40
 constexpr int RK_GLEVELS = 6;           // sparse table over the groups: spans up to 32 of them
 static_assert(RK_SB == 4 || RK_SB == 8, "a sub-block is one or two 16-byte LDS reads of sort words");
-static_assert(RK_NSB % 64 == 0 && RK_NGRP <= 64 && (1 << RK_GLEVELS) > RK_NGRP && RK_NSB <= RK_THREADS,
-              "group scans are laid out for whole waves");
+template <int CAP>
+struct RkGeom {
+  static constexpr int NSB = CAP / RK_SB;     // sub-blocks of the region
+  static constexpr int NGRP = NSB / RK_GRP;   // groups of sub-blocks
+  static_assert(CAP <= RK_CAP_MAX && CAP > RK_ROWS + RK_FWD, "region = rows before + the tile + rows after");
+  static_assert(NSB % 64 == 0 && NGRP <= 64 && (1 << RK_GLEVELS) > NGRP && NSB <= RK_THREADS,
+                "group scans are laid out for whole waves");
+};
 
 // ---- DPP moves inside a 16-lane row (used by the min / max scans over groups of sub-blocks)
 template <int CTRL>
@@ -131,8 +136,9 @@ __device__ __forceinline__ constexpr int xi(int e) { return e + (int)((unsigned)
 // slots beyond its end.
 constexpr int RK_NULL_AT = RK_SB;
 
-template <typename T>
+template <typename T, int RK_CAP>
 struct RsShared {
+  static constexpr int RK_NSB = RkGeom<RK_CAP>::NSB;
   static constexpr bool kIntT = ((T)0.5 == (T)0);
   uint32_t ck[RK_CAP];       // ((sort word >> low) - base, saturated) << 1 | metric-not-NULL
   // metric; for double a NULL slot holds NaN.  Slot e lives at xi(e): one spare element after every
@@ -159,14 +165,15 @@ struct RsShared {
   int nonfinite;  // some staged value is NaN or +-inf
 };
 
-template <typename T>
+template <typename T, int RK_CAP>
 __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_kernel(const uint64_t *comp,
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
                                                                  uint64_t w, RsOut<T> o,
                                                                  int32_t *deferred, int n_tiles) {
   constexpr bool kInt = ((T)0.5 == (T)0);
-  __shared__ RsShared<T> s;
+  constexpr int RK_NSB = RkGeom<RK_CAP>::NSB, RK_NGRP = RkGeom<RK_CAP>::NGRP;
+  __shared__ RsShared<T, RK_CAP> s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int low = lay.low_bits;
   const uint64_t pmask = lay.prim_mask();
@@ -654,15 +661,45 @@ static void rs_spec(const tmp_range_stats_args *a, OrderSpec *s) {
 
 // One metric column in sorted order -> its seven output columns: the region kernel, then (when some
 // frame left a block's region, which costs one small blocking read to learn) the wide path.
+// Slots of the region the kernel stages for these rows: the smallest of the three sizes whose reach
+// back (the region less the tile and the rows after it) is at least 1.25 x the rows a frame holds if
+// the rows are spread evenly over the keys and the time span.  Rows bunched more than that leave the
+// region and take the wide path -- as they do, later, with the largest region.  TEMPO_RK_CAP pins a size.
+static int rs_region_cap(int64_t n, int64_t n_keys, const Layout &lay, uint64_t w) {
+  if (const char *e = getenv("TEMPO_RK_CAP")) {
+    const int c = atoi(e);
+    if (c == 1536 || c == 2048 || c == 2560) return c;
+  }
+  const double span = (double)((uint64_t)lay.prim_max - (uint64_t)lay.prim_min) + 1.0;
+  const double est = ((double)w + 1.0) * (double)n / (span * (double)(n_keys > 0 ? n_keys : 1));
+  if (est * 1.25 <= 1536 - RK_ROWS - RK_FWD) return 1536;
+  if (est * 1.25 <= 2048 - RK_ROWS - RK_FWD) return 2048;
+  return 2560;
+}
+
 template <typename T>
-static int rs_column(const OrderResult &res, const T *xs, int64_t n, const Layout &lay, uint64_t w, const RsOut<T> &o,
-                     int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st) {
+static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_keys, const Layout &lay, uint64_t w,
+                     const RsOut<T> &o, int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st) {
   const int n_tiles = (int)((n + RK_ROWS - 1) / RK_ROWS);
   int grid = (n_tiles + 7) / 8 * 8;
   TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
   const uint32_t *perm = (const void *)res.perm == (const void *)o.perm ? nullptr : res.perm;
-  TMP_LAUNCH(range_stats_kernel<T>, dim3(grid), dim3(RK_THREADS), st, res.comp, perm, xs, n, lay, w, o,
-             deferred_flag, n_tiles);
+  {
+    ProfScope ps("range_stats_kernel<T>", st);
+    switch (rs_region_cap(n, n_keys, lay, w)) {
+      case 1536:
+        hipLaunchKernelGGL((range_stats_kernel<T, 1536>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
+                           o, deferred_flag, n_tiles);
+        break;
+      case 2048:
+        hipLaunchKernelGGL((range_stats_kernel<T, 2048>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
+                           o, deferred_flag, n_tiles);
+        break;
+      default:
+        hipLaunchKernelGGL((range_stats_kernel<T, 2560>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
+                           o, deferred_flag, n_tiles);
+    }
+  }
   TMP_CHECK_HIP(hipGetLastError());
   int32_t deferred = 0;
   TMP_CHECK_HIP(hipMemcpyAsync(&deferred, deferred_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -703,7 +740,7 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
   o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
   o.vbit = 0;
-  return rs_column<T>(res, xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
+  return rs_column<T>(res, xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
 }
 
 // Several metric columns over one ordering (tmp_range_stats_cols).
@@ -847,7 +884,7 @@ extern "C" int tmp_range_stats_cols(const tmp_range_stats_cols_args *a, void *wo
       o.mn = (int64_t *)a->out_min[c]; o.mx = (int64_t *)a->out_max[c]; o.sum = (int64_t *)a->out_sum[c];
       o.stddev = a->out_stddev[c]; o.zscore = a->out_zscore[c]; o.valid = a->out_valid[c];
       o.vbit = c;
-      rc = rs_column<int64_t>(res, (const int64_t *)xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred,
+      rc = rs_column<int64_t>(res, (const int64_t *)xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred,
                               have_wide, p.wide, st);
     } else {
       RsOut<double> o;
@@ -855,7 +892,7 @@ extern "C" int tmp_range_stats_cols(const tmp_range_stats_cols_args *a, void *wo
       o.mn = (double *)a->out_min[c]; o.mx = (double *)a->out_max[c]; o.sum = (double *)a->out_sum[c];
       o.stddev = a->out_stddev[c]; o.zscore = a->out_zscore[c]; o.valid = a->out_valid[c];
       o.vbit = c;
-      rc = rs_column<double>(res, (const double *)xs, a->n, lay, (uint64_t)a->range_back_secs, o, p.deferred,
+      rc = rs_column<double>(res, (const double *)xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred,
                              have_wide, p.wide, st);
     }
     TMP_TRY(rc);

@@ -412,3 +412,19 @@ def test_range_stats_several_columns_long_frames(orc, ops):
         g, ref = _compare(orc, ops, key, ts, xs[c], xv[c], nk, 120)
         for name in ("mean", "count", "min", "max", "sum", "stddev", "zscore", "valid"):
             assert np.array_equal(outs[c][name].cpu().numpy(), g[name], equal_nan=True), (c, name)
+
+
+@pytest.mark.parametrize("cap", [1536, 2048, 2560])
+@pytest.mark.parametrize("window", [120, 600])
+def test_range_stats_every_region_size(orc, ops, monkeypatch, cap, window):
+    """The statistics kernel stages a region of 1536, 2048 or 2560 rows around its 1024 (picked from the
+    expected rows per frame): each size gives the oracle's numbers, also where frames are longer than the
+    size reaches back (those rows take the wide path) -- and so does the size the library picks itself."""
+    rng = np.random.default_rng(40 + window)
+    key, ts, x, xv = _ticks(rng, 150_000, 7, 1.0, 0.01)
+    monkeypatch.setenv("TEMPO_RK_CAP", str(cap))
+    forced, _ = _compare(orc, ops, key, ts, x, xv, 7, window)
+    monkeypatch.delenv("TEMPO_RK_CAP")
+    picked, _ = _compare(orc, ops, key, ts, x, xv, 7, window)
+    for name in ("count", "min", "max", "valid"):
+        assert np.array_equal(forced[name], picked[name], equal_nan=forced[name].dtype.kind == "f"), name
