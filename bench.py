@@ -158,6 +158,7 @@ KERNEL_BYTES_PER_ROW = {
     "lastnn_scan_kernel<false>": 16.0,       # word 8 in, 2 x 4 B out
     "lastnn_reduce_kernel<false>": 8.0,
     "range_scan_kernel": 12.0,        # key 4 + ts 8 in
+    "range_scan_kernel+keys": 12.0,   # the same, leaving the key column's histogram for the first radix pass
     "make_comp_kernel": 24.0,         # key 4 + ts 8 in, word 8 + id 4 out (+ mask bytes on the right side)
 }
 

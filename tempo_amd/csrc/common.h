@@ -121,7 +121,9 @@ struct RangeInfo {
   // rows are probably in order already (a feed of interleaved devices whose clocks are not aligned).
   int32_t key_pairs;
   int32_t key_viol;
-  int32_t pad_;
+  // set by a sample of adjacent rows taken before the scan: the rows look time-ordered, and the scan
+  // took the form that also leaves the key column's histogram for the first radix pass
+  int32_t key_hist;
   int64_t desc_pos[15];
 };
 constexpr int kMaxDesc = 15;   // at most kMaxDesc + 1 = 16 runs are merged; more: a full sort
@@ -160,6 +162,11 @@ struct OrderBuffers {
   int64_t *run_cuts;             // [tiles + 1][kMaxRuns] rows of every run before each output tile
   uint64_t *carry[2 * 4];        // [column][2] ping-pong copies of payload columns that travel with the rows
   int carry_cols;
+  // host side: `counts` holds the histogram of (key & key_hist_mask) over key_hist_n rows in the block
+  // geometry of the first pass that builds its own words (left there by the range scan); 0 = it does not
+  int64_t key_hist_n;
+  uint32_t key_hist_mask;
+  const void *key_hist_of;  // the key column it was taken over
 };
 
 struct OrderResult {

@@ -59,7 +59,7 @@ __global__ void range_init_kernel(RangeInfo *r) {
   r->n_desc = 0;
   r->key_pairs = 0;
   r->key_viol = 0;
-  r->pad_ = 0;
+  r->key_hist = 0;
   for (int i = 0; i < kMaxDesc; ++i) r->desc_pos[i] = 0;
 }
 
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
                                                             const int64_t *ts, int64_t div,
                                                             const int64_t *seq,
                                                             const uint8_t *seq_valid,
-                                                            RangeInfo *out) {
+                                                            RangeInfo *out, int skip_if_key_hist) {
+  if (skip_if_key_hist && out->key_hist) return;  // the form that also counts the keys is doing the job
   int64_t pmin = INT64_MAX, pmax = INT64_MIN, smin = INT64_MAX, smax = INT64_MIN;
   int bad = 0, tbad = 0, nk = 0, nm = 0;
   // granularity is looked for in raw timestamp columns only, and a wave stops looking once one
@@ -218,6 +219,129 @@ __global__ __launch_bounds__(kBlock) void range_scan_kernel(int64_t n, const int
     if (tbad && !__atomic_load_n(&out->time_unsorted, __ATOMIC_RELAXED)) atomicOr(&out->time_unsorted, 1);
     if (nk && !__atomic_load_n(&out->not_thousands, __ATOMIC_RELAXED)) atomicOr(&out->not_thousands, 1);
     if (nm && !__atomic_load_n(&out->not_millions, __ATOMIC_RELAXED)) atomicOr(&out->not_millions, 1);
+  }
+}
+
+// range_scan_kernel for a table with a key column and no sequence column, in the block geometry of
+// the first radix pass (block b owns tiles_per_block tiles of RH_TILE consecutive rows): besides the
+// ranges it leaves counts[digit][block] of the key column's low bits (key & mask) -- the histogram a
+// pass over the key field needs -- so that a time-ordered feed is not read a second time for it.
+// The key and time columns are 16-byte aligned (the caller has checked).
+constexpr int RH_THREADS = 1024;
+
+// 1024 pairs of adjacent rows spread over the table: key_hist = 1 if time steps back in none of them.
+// Steers which of the two scans runs; what it guesses wrong costs time, never correctness.
+__global__ __launch_bounds__(256) void time_order_sample_kernel(int64_t n, const int64_t *ts, RangeInfo *out) {
+  __shared__ int bad_s;
+  if (threadIdx.x == 0) bad_s = 0;
+  __syncthreads();
+  bool bad = false;
+  const int64_t step = (n - 1) / 1024;
+  for (int j = 0; j < 4; ++j) {
+    const int64_t p = (int64_t)(threadIdx.x * 4 + j) * step;
+    if (p + 1 < n) bad |= ts[p] > ts[p + 1];
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) bad_s = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) out->key_hist = bad_s ? 0 : 1;
+}
+
+template <int RH_TILE>
+__global__ __launch_bounds__(RH_THREADS) void range_scan_hist_kernel(int64_t n, const int32_t *key, const int64_t *ts,
+                                                                     int64_t div, RangeInfo *out, uint32_t *counts,
+                                                                     int tiles_per_block, uint32_t mask) {
+  constexpr int RH_WAVES = RH_THREADS / 64;
+  if (!out->key_hist) return;  // the sample says the rows are not time-ordered: the plain scan runs instead
+  __shared__ uint32_t hist[RH_WAVES][256];
+  for (int i = threadIdx.x; i < RH_WAVES * 256; i += RH_THREADS) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  int64_t pmin = INT64_MAX, pmax = INT64_MIN;
+  int bad = 0, tbad = 0, nk = 0, nm = 0;
+  bool gran = div == 1;
+  const int64_t begin = (int64_t)blockIdx.x * tiles_per_block * RH_TILE;
+  int64_t end = begin + (int64_t)tiles_per_block * RH_TILE;
+  if (end > n) end = n;
+  const int64_t c_end = end >> 2;  // whole groups of four rows (begin is a multiple of four)
+  for (int64_t c = (begin >> 2) + threadIdx.x; c < c_end; c += RH_THREADS) {
+    longlong2 a = reinterpret_cast<const longlong2 *>(ts)[2 * c];
+    longlong2 b = reinterpret_cast<const longlong2 *>(ts)[2 * c + 1];
+    int4 k = reinterpret_cast<const int4 *>(key)[c];
+    int64_t t[4] = {a.x, a.y, b.x, b.y};
+    int32_t kk[4] = {k.x, k.y, k.z, k.w};
+    int64_t tp = c > 0 ? ts[4 * c - 1] : t[0];
+    int32_t kp = c > 0 ? key[4 * c - 1] : kk[0];
+    if (div != 1) {
+      tp = floordiv_i64(tp, div);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = floordiv_i64(t[j], div);
+    }
+    if (c == 0) tp = t[0];
+    bool down[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (gran) {
+        nk |= !multiple_of_1000(t[j]);
+        nm |= !multiple_of_1000000(t[j]);
+      }
+      pmin = t[j] < pmin ? t[j] : pmin;
+      pmax = t[j] > pmax ? t[j] : pmax;
+      bool tdown = tp > t[j];
+      tbad |= tdown;
+      bad |= kp != kk[j] ? kp > kk[j] : tdown;
+      tp = t[j];
+      kp = kk[j];
+      down[j] = tdown;
+      atomicAdd(&hist[wave][(uint32_t)kk[j] & mask], 1u);
+    }
+    if (gran && __any(nk)) gran = false;
+    if (__any(down[0] | down[1] | down[2] | down[3])) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) note_descents(down[j], 4 * c + j, out);
+    }
+  }
+  // the last rows of a table whose length is not a multiple of four belong to the last block
+  if (end == n) {
+    for (int64_t i = (c_end << 2) + threadIdx.x; i < n; i += RH_THREADS) {
+      int64_t p = div == 1 ? ts[i] : floordiv_i64(ts[i], div);
+      if (gran) {
+        nk |= !multiple_of_1000(p);
+        nm |= !multiple_of_1000000(p);
+      }
+      pmin = p < pmin ? p : pmin;
+      pmax = p > pmax ? p : pmax;
+      bool down = false;
+      if (i > 0) {
+        const int32_t k0 = key[i - 1], k1 = key[i];
+        const int64_t p0 = div == 1 ? ts[i - 1] : floordiv_i64(ts[i - 1], div);
+        down = p0 > p;
+        tbad |= down;
+        bad |= k0 != k1 ? k0 > k1 : down;
+      }
+      atomicAdd(&hist[wave][(uint32_t)key[i] & mask], 1u);
+      if (__any(down)) note_descents(down, i, out);
+    }
+  }
+  pmin = wave_min(pmin);
+  pmax = wave_max(pmax);
+  bad = __any(bad);
+  tbad = __any(tbad);
+  if (div != 1) nk = 1;
+  nk = __any(nk);
+  nm = __any(nm) | nk;
+  if ((threadIdx.x & 63) == 0) {
+    if (pmin < __atomic_load_n(&out->prim_min, __ATOMIC_RELAXED)) atomicMin((long long *)&out->prim_min, (long long)pmin);
+    if (pmax > __atomic_load_n(&out->prim_max, __ATOMIC_RELAXED)) atomicMax((long long *)&out->prim_max, (long long)pmax);
+    if (bad && !__atomic_load_n(&out->unsorted, __ATOMIC_RELAXED)) atomicOr(&out->unsorted, 1);
+    if (tbad && !__atomic_load_n(&out->time_unsorted, __ATOMIC_RELAXED)) atomicOr(&out->time_unsorted, 1);
+    if (nk && !__atomic_load_n(&out->not_thousands, __ATOMIC_RELAXED)) atomicOr(&out->not_thousands, 1);
+    if (nm && !__atomic_load_n(&out->not_millions, __ATOMIC_RELAXED)) atomicOr(&out->not_millions, 1);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < 256; d += RH_THREADS) {
+    uint32_t c = 0;
+    for (int w = 0; w < RH_WAVES; ++w) c += hist[w][d];
+    counts[(size_t)d * gridDim.x + blockIdx.x] = c;
   }
 }
 
@@ -385,6 +509,10 @@ struct SortGeom {
   int grid;
   int tiles_per_block;
 };
+#ifndef TEMPO_FUSED_ITEMS
+#define TEMPO_FUSED_ITEMS 8
+#endif
+constexpr int kFusedItems = TEMPO_FUSED_ITEMS;  // rows per thread of a first pass that also builds the words (their inputs need registers)
 
 static SortGeom sort_geom(int64_t n, int tile) {
   int64_t tiles = (n + tile - 1) / tile;
@@ -1711,6 +1839,9 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, int c
   b->max_buckets = 0;
   b->run_if = nullptr;
   b->carry_cols = 0;
+  b->key_hist_n = 0;
+  b->key_hist_mask = 0;
+  b->key_hist_of = nullptr;
   for (int c = 0; c < 2 * kMaxPay; ++c) b->carry[c] = nullptr;
   b->n_runs = 0;
   b->run_cuts = ws.take<int64_t>((size_t)(n / TS_CAP + 3) * kMaxRuns);
@@ -1817,10 +1948,34 @@ __global__ __launch_bounds__(kBlock) void ordered_check_kernel(const uint64_t *w
 
 int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
   TMP_LAUNCH(range_init_kernel, dim3(1), dim3(1), st, b.range);
+  b.key_hist_n = 0;
   if (s.n > 0) {
-    int grid = grid_for(s.n, kBlock * 16, 4096);
-    TMP_LAUNCH(range_scan_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts,
-                       s.prim_div, s.seq, s.seq_valid, b.range);
+    // A large table with a short key dictionary and no sequence column may turn out to be a
+    // time-ordered feed, whose one pass over the key field wants the histogram of the key column: the
+    // scan reads that column anyway and leaves the histogram behind (sort_geom of the pass that uses it).
+    const int key_bits = s.key ? bits_for((uint64_t)(s.n_keys > 1 ? s.n_keys - 1 : 0)) : 0;
+    const bool with_hist = s.key && !s.seq && key_bits >= 1 && key_bits <= 8 && s.n >= (1 << 20) &&
+                           (((uintptr_t)s.ts | (uintptr_t)s.key) & 15) == 0 && !getenv("TEMPO_NO_FUSED_WORDS") &&
+                           !getenv("TEMPO_NO_SCAN_HIST");
+    if (with_hist) {
+      const SortGeom g = sort_geom(s.n, 1024 * kFusedItems);
+      const uint32_t mask = (1u << key_bits) - 1;
+      // which of the two scans does the work is settled on the device, by a sample of adjacent rows
+      TMP_LAUNCH(time_order_sample_kernel, dim3(1), dim3(256), st, s.n, s.ts, b.range);
+      {
+        ProfScope ps("range_scan_kernel+keys", st);
+        hipLaunchKernelGGL((range_scan_hist_kernel<1024 * kFusedItems>), dim3(g.grid), dim3(RH_THREADS), 0, st, s.n, s.key,
+                           s.ts, s.prim_div, b.range, b.counts, g.tiles_per_block, mask);
+      }
+      b.key_hist_n = s.n;  // (dropped again when the record read back says the plain scan ran)
+      b.key_hist_mask = mask;
+      b.key_hist_of = s.key;
+    }
+    {
+      int grid = grid_for(s.n, kBlock * 16, 4096);
+      TMP_LAUNCH(range_scan_kernel, dim3(grid), dim3(kBlock), st, s.n, s.key, s.ts,
+                 s.prim_div, s.seq, s.seq_valid, b.range, with_hist ? 1 : 0);
+    }
     if (s.key && s.n >= kKoMinRows && !getenv("TEMPO_NO_KEY_ORDER"))
       TMP_LAUNCH(key_order_sample_kernel, dim3(kKoWindows), dim3(64), st, s.n, s.key, s.ts, s.prim_div, s.seq,
                  s.seq_valid, b.range);
@@ -1832,6 +1987,7 @@ int order_scan_ranges(const OrderSpec &s, OrderBuffers &b, hipStream_t st) {
 int order_read_ranges(OrderBuffers &b, RangeInfo *host, hipStream_t st) {
   TMP_CHECK_HIP(hipMemcpyAsync(host, b.range, sizeof(RangeInfo), hipMemcpyDeviceToHost, st));
   TMP_CHECK_HIP(hipStreamSynchronize(st));
+  if (!host->key_hist) b.key_hist_n = 0;
   b.n_runs = 0;
   if (sorted_mode(*host) == 3) {  // a few time-ordered runs end to end: where each starts
     int64_t pos[kMaxDesc];
@@ -1923,10 +2079,16 @@ static void radix_first_pass_fused(OrderBuffers &b, int64_t n, int cur, int lo, 
                                    const PayPtrs &pp, const GenArgs &gen) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   const uint32_t mask = (1u << nbits) - 1;
+  // the range scan may have left this very histogram in b.counts (same rows, same tiles, the digit
+  // being the key's low bits: the pass starts at the key field's first bit)
+  const bool have_hist = b.key_hist_n == n && b.key_hist_mask == mask && b.key_hist_of == (const void *)gen.key && BITS == 8 && THREADS * ITEMS == 1024 * kFusedItems &&
+                         lo == gen.lay.key_shift() && !b.run_if;
+  b.key_hist_n = 0;
   {
     ProfScope ps("radix_hist_kernel+keys", st);
-    hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 3>), dim3(g.grid), dim3(THREADS), 0, st,
-                       (const uint64_t *)nullptr, n, lo, mask, g.tiles_per_block, b.counts, gen, (uint64_t *)nullptr, b.run_if);
+    if (!have_hist)
+      hipLaunchKernelGGL((radix_hist_kernel<THREADS, ITEMS, BITS, 3>), dim3(g.grid), dim3(THREADS), 0, st,
+                         (const uint64_t *)nullptr, n, lo, mask, g.tiles_per_block, b.counts, gen, (uint64_t *)nullptr, b.run_if);
     TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid, b.run_if);
   }
   {
@@ -1949,6 +2111,7 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
   const int shift = lo + (pack ? id_bits : 0);
   GenArgs none;
   memset(&none, 0, sizeof(none));
+  b.key_hist_n = 0;  // whatever the range scan left in b.counts is about to be overwritten
   if (!hist_done) {
     ProfScope ps(gen ? "radix_hist_kernel+words" : "radix_hist_kernel", st);
     if (gen && gen->id_bits)
@@ -1979,10 +2142,6 @@ static void radix_one_pass_t(OrderBuffers &b, int64_t n, int cur, int lo, int nb
 #define TEMPO_RS_ITEMS 12
 #endif
 constexpr int kPlainItems = TEMPO_RS_ITEMS;  // rows per thread of the passes that move pairs (and travelling columns) only
-#ifndef TEMPO_FUSED_ITEMS
-#define TEMPO_FUSED_ITEMS 8
-#endif
-constexpr int kFusedItems = TEMPO_FUSED_ITEMS;  // ... of a first pass that also builds the words (their inputs need registers)
 
 template <int THREADS, int ITEMS, int NPAY>
 static void radix_one_pass(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,

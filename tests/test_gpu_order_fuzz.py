@@ -65,7 +65,10 @@ def test_order_fuzz(orc, monkeypatch, shape, n, n_keys, with_seq, floor_seconds,
 
 @pytest.mark.parametrize("n,n_keys,shape", [(5_000, 2, "time"), (70_001, 100, "time"), (1_200_000, 300, "time"),
                                             (300_000, 200, "per_key"), (1_100_000, 9, "per_key"),
-                                            (8_193, 256, "time"), (16_384, 1, "time")])
+                                            (8_193, 256, "time"), (16_384, 1, "time"),
+                                            # 2^20 rows and more, at most 256 keys: the range scan leaves the
+                                            # key histogram behind, the pass runs no histogram kernel of its own
+                                            (1_300_003, 100, "time"), (1_048_576, 2, "time")])
 def test_time_ordered_first_pass_builds_its_words(orc, monkeypatch, n, n_keys, shape):
     """A time-ordered (or per-key-ordered) feed takes one pass over the key bits whose scatter builds
     the sort words itself from the key / time / validity columns: the order, the ordered metric and the
