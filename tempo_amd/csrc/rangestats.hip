@@ -682,29 +682,36 @@ static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_k
                      const RsOut<T> &o, int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st) {
   const int n_tiles = (int)((n + RK_ROWS - 1) / RK_ROWS);
   int grid = (n_tiles + 7) / 8 * 8;
-  TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
   const uint32_t *perm = (const void *)res.perm == (const void *)o.perm ? nullptr : res.perm;
-  {
-    ProfScope ps("range_stats_kernel<T>", st);
-    switch (rs_region_cap(n, n_keys, lay, w)) {
-      case 1536:
-        hipLaunchKernelGGL((range_stats_kernel<T, 1536>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
-                           o, deferred_flag, n_tiles);
-        break;
-      case 2048:
-        hipLaunchKernelGGL((range_stats_kernel<T, 2048>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
-                           o, deferred_flag, n_tiles);
-        break;
-      default:
-        hipLaunchKernelGGL((range_stats_kernel<T, 2560>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay, w,
-                           o, deferred_flag, n_tiles);
+  // the region picked from the expected rows per frame; if some frame left it after all (rows bunched
+  // where the estimate assumed an even spread), once more with the largest region before anything else
+  int cap = rs_region_cap(n, n_keys, lay, w);
+  for (;;) {
+    TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
+    {
+      ProfScope ps("range_stats_kernel<T>", st);
+      switch (cap) {
+        case 1536:
+          hipLaunchKernelGGL((range_stats_kernel<T, 1536>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                             w, o, deferred_flag, n_tiles);
+          break;
+        case 2048:
+          hipLaunchKernelGGL((range_stats_kernel<T, 2048>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                             w, o, deferred_flag, n_tiles);
+          break;
+        default:
+          hipLaunchKernelGGL((range_stats_kernel<T, 2560>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                             w, o, deferred_flag, n_tiles);
+      }
     }
+    TMP_CHECK_HIP(hipGetLastError());
+    int32_t deferred = 0;
+    TMP_CHECK_HIP(hipMemcpyAsync(&deferred, deferred_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TMP_CHECK_HIP(hipStreamSynchronize(st));
+    if (!deferred) return TMP_OK;
+    if (cap == RK_CAP_MAX || getenv("TEMPO_RK_CAP")) break;
+    cap = RK_CAP_MAX;
   }
-  TMP_CHECK_HIP(hipGetLastError());
-  int32_t deferred = 0;
-  TMP_CHECK_HIP(hipMemcpyAsync(&deferred, deferred_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  TMP_CHECK_HIP(hipStreamSynchronize(st));
-  if (!deferred) return TMP_OK;
   if (!have_wide) {
     set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
               "tmp_range_stats_wide_workspace_bytes() bytes");

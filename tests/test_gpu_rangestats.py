@@ -428,3 +428,25 @@ def test_range_stats_every_region_size(orc, ops, monkeypatch, cap, window):
     picked, _ = _compare(orc, ops, key, ts, x, xv, 7, window)
     for name in ("count", "min", "max", "valid"):
         assert np.array_equal(forced[name], picked[name], equal_nan=forced[name].dtype.kind == "f"), name
+
+
+def test_range_stats_bunched_rows_get_the_large_region(orc, ops):
+    """Rows spread thinly over a long period, except for a burst that puts 1000 rows into one frame: the
+    estimate of rows per frame picks the smallest region, the burst's frames leave it, and the column is
+    run once more with the largest region (which holds them) -- not sent down the wide path."""
+    from tempo_amd import _lib
+    rng = np.random.default_rng(77)
+    n, nk = 120_000, 3
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + np.sort(rng.integers(0, 400_000, n)) * 1_000_000          # ~0.1 rows per second and key
+    burst = slice(50_000, 53_000)
+    ts[burst] = ts[50_000] + np.sort(rng.integers(0, 300, 3_000)) * 1_000_000   # 1000 rows per key within 300 s
+    ts = np.sort(ts)
+    x = 50 + rng.normal(0, 1, n).cumsum() * 0.01
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    _compare(orc, ops, key, ts, x, None, nk, 600)
+    names = [name for name, _, _ in _lib.profile_read()]
+    _lib.profile_enable(False)
+    assert names.count("range_stats_kernel<T>") == 2, names
+    assert not any("wide" in name for name in names), names
