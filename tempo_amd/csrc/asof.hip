@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
                                                                  int n_masks,
                                                                  int64_t rows_per_unit, int units,
                                                                  const int32_t *unit_agg,
-                                                                 int32_t *lastnn, const uint16_t *ext) {
+                                                                 int32_t *lastnn, const uint16_t *ext, int sparse) {
+  // sparse: entries of rows whose own bit is set (lastnn = the row itself) are left unwritten -- the
+  // reader has the row's bits in hand and asks only about rows whose bit is clear
   int unit = blockIdx.x * (kUnitBlock / 64) + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (unit >= units) return;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kUnitBlock) void lastnn_scan_kernel(const uint64_t 
           uint64_t bal = __ballot((w[r] >> m) & 1ull);
           uint64_t le = bal & le_mask;
           int32_t j = le ? (int32_t)(base + r * 64 + 63 - __clzll((long long)le)) : carry[m];
-          if (i < end) {
+          if (i < end && !(sparse && ((w[r] >> m) & 1ull))) {
             if (REV) lastnn[(size_t)m * n + (n - 1 - i)] = j < 0 ? -1 : (int32_t)(n - 1 - j);
             else lastnn[(size_t)m * n + i] = j;
           }
@@ -182,7 +184,7 @@ int last_valid_unit_carry(int32_t *unit_agg, int units, int n_masks, hipStream_t
 }
 
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
-                    bool reverse, hipStream_t st, const uint16_t *ext) {
+                    bool reverse, hipStream_t st, const uint16_t *ext, bool sparse) {
   if (n <= 0 || n_masks <= 0) return TMP_OK;
   ScanGeom g = scan_geom(n);
   int blocks = (g.units + (kUnitBlock / 64) - 1) / (kUnitBlock / 64);
@@ -191,13 +193,13 @@ int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_
                g.rows_per_unit, g.units, unit_agg, ext);
     TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
     TMP_LAUNCH(lastnn_scan_kernel<true>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg, out, ext);
+               g.rows_per_unit, g.units, unit_agg, out, ext, sparse ? 1 : 0);
   } else {
     TMP_LAUNCH(lastnn_reduce_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
                g.rows_per_unit, g.units, unit_agg, ext);
     TMP_LAUNCH(lastnn_carry_kernel, dim3(n_masks), dim3(1024), st, unit_agg, g.units);
     TMP_LAUNCH(lastnn_scan_kernel<false>, dim3(blocks), dim3(kUnitBlock), st, comp, n, n_masks,
-               g.rows_per_unit, g.units, unit_agg, out, ext);
+               g.rows_per_unit, g.units, unit_agg, out, ext, sparse ? 1 : 0);
   }
   TMP_CHECK_HIP(hipGetLastError());
   return TMP_OK;
@@ -358,8 +360,11 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
     uint32_t dst = sorted_output ? (uint32_t)i : src_row;
     int32_t jpre[4];
 #pragma unroll
+    // a matched row whose own bit is set is its own last valid row (the scan does not even write
+    // that entry when the bits ride in the words); the array is asked about the others only
     for (int mm = 0; mm < 4; ++mm)
-      jpre[mm] = (same && mm < n_masks) ? lastnn[(size_t)mm * n_right + jr] : -1;
+      jpre[mm] = (same && mm < n_masks) ? ((!cmask && ((wr_row >> mm) & 1ull)) ? (int32_t)jr : lastnn[(size_t)mm * n_right + jr])
+                                        : -1;
     if (sorted_output && out_perm) {
       if (perm_l) out_perm[i] = (int32_t)src_row;  // null: the ordering step left the row ids in out_perm itself
       if (out_key) out_key[i] = (int32_t)key_l;
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void asof_merge_kernel(
       uint64_t wm = 0;
       if (same) {
         int32_t j = m == 0 ? jpre[0] : m == 1 ? jpre[1] : m == 2 ? jpre[2] : m == 3 ? jpre[3]
-                                                                  : lastnn[(size_t)m * n_right + jr];
+                    : ((!cmask && ((wr_row >> m) & 1ull)) ? (int32_t)jr : lastnn[(size_t)m * n_right + jr]);
         if (j >= 0) {
           // two typed loads, not one load through a pointer chosen at run time (that becomes
           // a flat access, which waits on every outstanding global and LDS operation)
@@ -765,7 +770,7 @@ extern "C" int tmp_asof_join(const tmp_asof_args *a, void *workspace, size_t wor
     TMP_TRY(order_gather_masks(rs, ro, p.cmask, rst));
     cmask = p.cmask;
   }
-  TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, rst, cmask));
+  TMP_TRY(last_valid_scan(ro.comp, a->n_right, a->n_masks, p.unit_agg, p.lastnn, false, rst, cmask, cmask == nullptr));
   TMP_CHECK_HIP(side_join.join());
   int grid = (int)((a->n_left + kBlock * kMergeRows - 1) / (kBlock * kMergeRows));
   TMP_LAUNCH(merge_bounds_kernel, dim3((grid + 1 + kBlock - 1) / kBlock), dim3(kBlock), st, lo.comp, a->n_left, ro.comp,

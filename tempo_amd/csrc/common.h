@@ -236,7 +236,7 @@ int order_gather_masks(const OrderSpec &s, const OrderResult &res, uint16_t *out
 size_t last_valid_scratch_ints();
 // ext: the mask bits as a separate array (Layout::ext_masks) instead of the words' low bits.
 int last_valid_scan(const uint64_t *comp, int64_t n, int n_masks, int32_t *unit_agg, int32_t *out,
-                    bool reverse, hipStream_t st, const uint16_t *ext = nullptr);
+                    bool reverse, hipStream_t st, const uint16_t *ext = nullptr, bool sparse = false);
 // The scan works in kLastValidUnits slices ("units"); unit_agg is laid out [mask][kLastValidUnits].
 constexpr int kLastValidUnits = 4096;
 // In place, per mask m < n_masks: unit_agg[m][u] (last set position inside unit u, or -1) becomes the
