@@ -292,7 +292,19 @@ __global__ __launch_bounds__(RH_THREADS) void range_scan_hist_kernel(int64_t n, 
       tp = t[j];
       kp = kk[j];
       down[j] = tdown;
-      atomicAdd(&hist[wave][(uint32_t)kk[j] & mask], 1u);
+    }
+    // keys that come in long stretches (a table ordered by key) would send all 64 lanes to one
+    // counter: a wave whose lanes all hold one key adds its rows up in a single update
+    const uint32_t k_first = (uint32_t)__builtin_amdgcn_readfirstlane(kk[0]) & mask;
+    bool one_key = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) one_key &= ((uint32_t)kk[j] & mask) == k_first;
+    if (__all(one_key)) {
+      const uint64_t act = __ballot(true);
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&hist[wave][k_first], 4u * (uint32_t)__popcll(act));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(&hist[wave][(uint32_t)kk[j] & mask], 1u);
     }
     if (gran && __any(nk)) gran = false;
     if (__any(down[0] | down[1] | down[2] | down[3])) {
@@ -2290,9 +2302,12 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   gen.vec4 = gen_vector_ok(gen) ? 1 : 0;
   const int lo_bit = sorted == 2 ? lay.key_shift() : lay.low_bits, hi_bit = lay.total_bits();
   if (sorted == 1 || lo_bit >= hi_bit) {  // no pass to run: the words in input order are the result
+    // (the row ids go to the second id buffer: where a caller has put its own output array in that
+    // buffer's place -- as for an ordering that ends there -- they are where they belong at once)
     int grid = grid_for(s.n, kBlock * 4, 8192);
-    TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, gen, b.comp[0], b.idx[0]);
+    TMP_LAUNCH(make_comp_kernel, dim3(grid), dim3(kBlock), st, s.n, gen, b.comp[0], b.idx[1]);
     TMP_CHECK_HIP(hipGetLastError());
+    res->perm = b.idx[1];
     return TMP_OK;
   }
   if (sorted == 3 && (lay.seq_wide || !b.run_cuts || b.n_runs < 2 || b.n_runs > kMaxRuns ||

@@ -114,10 +114,11 @@ extern "C" int tmp_write_layout(const tmp_write_layout_args *a, void *workspace,
                (int32_t)day_max);
   if (day_max > day_min) {
     // the ordered pair of buffers becomes the input side of the extra passes
-    const int at = res.comp == b.comp[0] ? 0 : 1;
+    // (words and row ids may have ended in different halves of their ping-pong pairs)
+    const int at = res.comp == b.comp[0] ? 0 : 1, at_ids = res.perm == b.idx[0] ? 0 : 1;
     OrderBuffers b2 = b;
-    b2.comp[0] = b.comp[at]; b2.idx[0] = b.idx[at];
-    b2.comp[1] = b.comp[at ^ 1]; b2.idx[1] = b.idx[at ^ 1];
+    b2.comp[0] = b.comp[at]; b2.idx[0] = b.idx[at_ids];
+    b2.comp[1] = b.comp[at ^ 1]; b2.idx[1] = b.idx[at_ids ^ 1];
     TMP_LAUNCH(day_digit_kernel, dim3(grid), dim3(kBlock), st, a->n, b2.comp[0], lay, day_min);
     TMP_TRY(order_radix_passes(b2, a->n, 0, bits_for((uint64_t)(day_max - day_min)), &res, st));
   }
