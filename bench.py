@@ -435,6 +435,23 @@ def main():
         sorted_ms = e0.elapsed_time(e1) / 3
         del sq
 
+    # ---- the same withRangeStats on the tick table laid out in (key, ts) order (not part of `value`):
+    # no ordering pass at all, the row ids are the positions
+    stats_sorted_ms = None
+    if rank == 0 and args.gpus == 1 and not args.no_shuffled:
+        o = torch.argsort(tk["key"], stable=True)   # the feed is time-ordered: a stable sort by key gives (key, ts)
+        ts_k = {k: v[o].contiguous() for k, v in tk.items()}
+        del o
+        ops.range_stats(ts_k["key"], ts_k["ts"], ts_k["x"], ts_k["x_valid"], TICK_KEYS, 600)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            ops.range_stats(ts_k["key"], ts_k["ts"], ts_k["x"], ts_k["x_valid"], TICK_KEYS, 600)
+        e1.record()
+        torch.cuda.synchronize()
+        stats_sorted_ms = e0.elapsed_time(e1) / 2
+        del ts_k
+
     # ---- CPU baseline: the C oracle (a port of the reference plan) on a bounded sample, 1 core
     cpu = None
     if rank == 0 and args.gpus == 1 and args.cpu_sample > 0:
@@ -484,6 +501,7 @@ def main():
                 "rows_held_per_rank": rows_per_rank,
                 "range_stats_shuffled_ms_per_step": None if shuffled_ms is None else round(shuffled_ms, 3),
                 "asof_sorted_input_ms_per_step": None if sorted_ms is None else round(sorted_ms, 3),
+                "range_stats_sorted_input_ms_per_step": None if stats_sorted_ms is None else round(stats_sorted_ms, 3),
                 "peak_hbm_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
