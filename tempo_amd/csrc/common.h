@@ -284,6 +284,17 @@ __device__ __forceinline__ int64_t floordiv_i64(int64_t a, int64_t b) {
   return q;
 }
 
+// The sort word of a row without a sequence column, from its loaded values (key id, time, NULL
+// mask bits): what make_word gives for plain (not bucketed) words.
+__device__ __forceinline__ uint64_t plain_word(const Layout &lay, int64_t ts, uint32_t key, uint32_t mask_bits) {
+  const int64_t p = lay.prim_div == 1 ? ts : floordiv_i64(ts, lay.prim_div);
+  uint64_t rel = (uint64_t)(p - lay.prim_min);
+  if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
+  uint64_t w = (rel << lay.prim_shift()) | mask_bits;
+  if (lay.key_bits) w |= (uint64_t)key << lay.key_shift();
+  return w;
+}
+
 // Optional per-kernel timing (tmp_profile_* in tempo_hip.h): a pair of HIP events around every
 // launch, recorded on the launch stream.  Off by default; costs nothing when off.
 struct ProfScope {

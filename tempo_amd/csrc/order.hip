@@ -409,17 +409,6 @@ __device__ __forceinline__ uint64_t make_word(const GenArgs &g, int64_t i) {
   return w;
 }
 
-// The sort word of a row without a sequence column, from its loaded values (key id, time, NULL
-// mask bits): what make_word gives for plain (not bucketed) words.
-__device__ __forceinline__ uint64_t plain_word(const Layout &lay, int64_t ts, uint32_t key, uint32_t mask_bits) {
-  const int64_t p = lay.prim_div == 1 ? ts : floordiv_i64(ts, lay.prim_div);
-  uint64_t rel = (uint64_t)(p - lay.prim_min);
-  if (lay.prim_gran != 1) rel = (uint64_t)floordiv_i64((int64_t)rel, lay.prim_gran);
-  uint64_t w = (rel << lay.prim_shift()) | mask_bits;
-  if (lay.key_bits) w |= (uint64_t)key << lay.key_shift();
-  return w;
-}
-
 // The (time, sequence) part of row i's sort word, as a number: ordering by it is ordering by
 // (primary, seq NULLS FIRST).  Not for layouts with seq_wide.
 __device__ __forceinline__ uint64_t time_of(const Layout &lay, int64_t ts, bool seq_ok, int64_t seq) {

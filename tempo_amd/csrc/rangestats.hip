@@ -165,12 +165,23 @@ struct RsShared {
   int nonfinite;  // some staged value is NaN or +-inf
 };
 
-template <typename T, int RK_CAP>
+// The table's own key / time / NULL-flag columns, for rows that are in (key, time) order already.
+struct RsSrc {
+  const int32_t *key;    // null: one series
+  const int64_t *ts;
+  const uint8_t *valid;  // null: no NULLs
+};
+
+// GENK: the rows are in order where they lie, and their sort words are not read from `comp` but built
+// here from the table's columns (src) -- nothing is laid out beforehand; out_perm is the identity.
+// What this form cannot finish (frames that leave the region, frames with NaN / inf) it marks as
+// deferred, and the caller runs the ordinary form over laid-out words.
+template <typename T, int RK_CAP, bool GENK>
 __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_kernel(const uint64_t *comp,
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
                                                                  uint64_t w, RsOut<T> o,
-                                                                 int32_t *deferred, int n_tiles) {
+                                                                 int32_t *deferred, int n_tiles, RsSrc src) {
   constexpr bool kInt = ((T)0.5 == (T)0);
   constexpr int RK_NSB = RkGeom<RK_CAP>::NSB, RK_NGRP = RkGeom<RK_CAP>::NGRP;
   __shared__ RsShared<T, RK_CAP> s;
@@ -190,7 +201,9 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   const int64_t rs = t0 - kBack > 0 ? t0 - kBack : 0;
   const int64_t re = t0 + RK_ROWS + RK_FWD < n ? t0 + RK_ROWS + RK_FWD : n;
   const int len = (int)(re - rs);
-  const uint64_t base = comp[rs] >> low;
+  uint64_t base;
+  if (GENK) base = plain_word(lay, src.ts[rs], src.key ? (uint32_t)src.key[rs] : 0u, 0u) >> low;
+  else base = comp[rs] >> low;
   if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; s.x[RK_NULL_AT] = MinMax<T>::null_slot(); }
   __syncthreads();
 #ifdef RK_TIMING
@@ -212,8 +225,22 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   for (int r = 0; r < kPer; ++r) {
     const int e = r * RK_THREADS + tid;
     const uint32_t at = (uint32_t)(e < len ? e : len - 1);  // (block-uniform base + 32-bit offset: one address register)
-    wd[r] = (comp + rs)[at];
+    if (!GENK) wd[r] = (comp + rs)[at];
     xv[r] = (xs + rs)[at];
+  }
+  if (GENK) {
+    int64_t tsv[kPer];
+    uint32_t kv[kPer], vv[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+      const int e = r * RK_THREADS + tid;
+      const uint32_t at = (uint32_t)(e < len ? e : len - 1);
+      tsv[r] = (src.ts + rs)[at];
+      kv[r] = src.key ? (uint32_t)(src.key + rs)[at] : 0u;
+      vv[r] = src.valid ? (uint32_t)(src.valid + rs)[at] : 1u;
+    }
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) wd[r] = plain_word(lay, tsv[r], kv[r], vv[r] ? 1u : 0u);
   }
 #pragma unroll
   for (int r = 0; r < kPer; ++r) {
@@ -462,7 +489,8 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     b = lo - 1;
   }
   RTICK();
-  if (perm) o.perm[i] = (int32_t)perm[i];  // null: the ordering step left the row ids in o.perm itself
+  if (GENK) o.perm[i] = (int32_t)i;
+  else if (perm) o.perm[i] = (int32_t)perm[i];  // null: the ordering step left the row ids in o.perm itself
   const bool open_left = a == 0 && rs > 0;          // the frame may start before the region
   const bool open_right = b == len - 1 && re < n;   // peers may continue after the region
   bool slow = open_left || open_right || krel >= RK_SAT;
@@ -574,7 +602,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   RTICK();
   // A frame that leaves the staged region (or a region too wide for 32-bit relative words) is
   // not evaluated here: the row is marked and the wide path completes it.
-  const bool defer = open_left || open_right || krel >= RK_SAT;
+  const bool defer = open_left || open_right || krel >= RK_SAT || (GENK && slow);  // (GENK: no laid-out words for the serial path)
   if (__any(defer) && lane == 0 && __atomic_load_n(deferred, __ATOMIC_RELAXED) == 0) atomicOr(deferred, 1);
   if (defer) {
     o.valid[i] = kDeferred;
@@ -677,33 +705,45 @@ static int rs_region_cap(int64_t n, int64_t n_keys, const Layout &lay, uint64_t 
   return 2560;
 }
 
+template <typename T, bool GENK>
+static void rs_launch(int cap, int grid, hipStream_t st, const OrderResult &res, const uint32_t *perm, const T *xs, int64_t n,
+                      const Layout &lay, uint64_t w, const RsOut<T> &o, int32_t *deferred_flag, int n_tiles, const RsSrc &src) {
+  ProfScope ps(GENK ? "range_stats_kernel<T>+words" : "range_stats_kernel<T>", st);
+  switch (cap) {
+    case 1536:
+      hipLaunchKernelGGL((range_stats_kernel<T, 1536, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                         w, o, deferred_flag, n_tiles, src);
+      break;
+    case 2048:
+      hipLaunchKernelGGL((range_stats_kernel<T, 2048, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                         w, o, deferred_flag, n_tiles, src);
+      break;
+    default:
+      hipLaunchKernelGGL((range_stats_kernel<T, 2560, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+                         w, o, deferred_flag, n_tiles, src);
+  }
+}
+
+constexpr int kRsNeedWords = 1000;  // rs_column with `src`: some rows need the ordinary form over laid-out words
+
+// src != nullptr: the rows are in order where they lie; the kernel builds the sort words itself (res is
+// not used).  Returns kRsNeedWords if some row could not be finished that way.
 template <typename T>
 static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_keys, const Layout &lay, uint64_t w,
-                     const RsOut<T> &o, int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st) {
+                     const RsOut<T> &o, int32_t *deferred_flag, bool have_wide, RsWidePlan &wide, hipStream_t st,
+                     const RsSrc *src = nullptr) {
   const int n_tiles = (int)((n + RK_ROWS - 1) / RK_ROWS);
   int grid = (n_tiles + 7) / 8 * 8;
-  const uint32_t *perm = (const void *)res.perm == (const void *)o.perm ? nullptr : res.perm;
+  const uint32_t *perm = (src || (const void *)res.perm == (const void *)o.perm) ? nullptr : res.perm;
+  RsSrc none;
+  memset(&none, 0, sizeof(none));
   // the region picked from the expected rows per frame; if some frame left it after all (rows bunched
   // where the estimate assumed an even spread), once more with the largest region before anything else
   int cap = rs_region_cap(n, n_keys, lay, w);
   for (;;) {
     TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
-    {
-      ProfScope ps("range_stats_kernel<T>", st);
-      switch (cap) {
-        case 1536:
-          hipLaunchKernelGGL((range_stats_kernel<T, 1536>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
-                             w, o, deferred_flag, n_tiles);
-          break;
-        case 2048:
-          hipLaunchKernelGGL((range_stats_kernel<T, 2048>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
-                             w, o, deferred_flag, n_tiles);
-          break;
-        default:
-          hipLaunchKernelGGL((range_stats_kernel<T, 2560>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
-                             w, o, deferred_flag, n_tiles);
-      }
-    }
+    if (src) rs_launch<T, true>(cap, grid, st, res, perm, xs, n, lay, w, o, deferred_flag, n_tiles, *src);
+    else rs_launch<T, false>(cap, grid, st, res, perm, xs, n, lay, w, o, deferred_flag, n_tiles, none);
     TMP_CHECK_HIP(hipGetLastError());
     int32_t deferred = 0;
     TMP_CHECK_HIP(hipMemcpyAsync(&deferred, deferred_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -712,6 +752,7 @@ static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_k
     if (cap == RK_CAP_MAX || getenv("TEMPO_RK_CAP")) break;
     cap = RK_CAP_MAX;
   }
+  if (src) return kRsNeedWords;
   if (!have_wide) {
     set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
               "tmp_range_stats_wide_workspace_bytes() bytes");
@@ -735,6 +776,21 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   Layout lay;
   TMP_TRY(order_make_layout(s, r, 1, &lay));
   OrderResult res;
+  RsOut<T> o;
+  o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
+  o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
+  o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
+  o.vbit = 0;
+  // rows that arrive in (key, second) order: nothing is laid out, the statistics kernel reads the
+  // table's own columns (TEMPO_NO_STATS_IN_PLACE=1: the words are laid out first, as for any table)
+  if (sorted_mode(r) == 1 && a->n > 0 && !getenv("TEMPO_NO_STATS_IN_PLACE")) {
+    RsSrc src;
+    src.key = a->key; src.ts = a->ts; src.valid = a->x_valid;
+    res.comp = nullptr; res.perm = nullptr;
+    const int rc = rs_column<T>(res, (const T *)a->x, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred,
+                                have_wide, p.wide, st, &src);
+    if (rc != kRsNeedWords) return rc;
+  }
   // the metric column rides along with the last radix pass; if no pass runs the rows are
   // already in order and the column is used where it is
   bool carried = false;
@@ -742,11 +798,6 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   uint64_t *pay_out[1] = {p.xs};
   TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
   const T *xs = carried ? (const T *)p.xs : (const T *)a->x;
-  RsOut<T> o;
-  o.perm = a->out_perm; o.mean = a->out_mean; o.count = a->out_count;
-  o.mn = (T *)a->out_min; o.mx = (T *)a->out_max; o.sum = (T *)a->out_sum;
-  o.stddev = a->out_stddev; o.zscore = a->out_zscore; o.valid = a->out_valid;
-  o.vbit = 0;
   return rs_column<T>(res, xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
 }
 

@@ -450,3 +450,40 @@ def test_range_stats_bunched_rows_get_the_large_region(orc, ops):
     _lib.profile_enable(False)
     assert names.count("range_stats_kernel<T>") == 2, names
     assert not any("wide" in name for name in names), names
+
+
+@pytest.mark.parametrize("case", ["plain", "nulls", "nonfinite", "long_frames", "one_series", "int_metric"])
+def test_range_stats_rows_in_order_need_no_words(orc, ops, monkeypatch, case):
+    """A table that arrives in (key, ts) order is aggregated where it lies: the kernel builds the sort
+    words from the key / time / NULL-flag columns, out_perm is the identity.  Frames with NaN / inf and
+    frames longer than the region send the call back to laid-out words; either way the numbers are the
+    oracle's and those of the call that lays the words out first."""
+    from tempo_amd import _lib
+    rng = np.random.default_rng(len(case))
+    n, nk = 90_000, 6
+    key, ts, x, xv = _ticks(rng, n, nk, 1.0, 0.05 if case != "plain" else 0.0, sort=True)
+    o = np.lexsort((ts, key))
+    key, ts, x = key[o], ts[o], x[o]
+    xv = None if xv is None else xv[o]
+    window = 300
+    if case == "nonfinite":
+        x[rng.integers(0, n, 40)] = rng.choice([np.nan, np.inf, -np.inf], 40)
+    if case == "long_frames":
+        window = 60000         # about 1650 rows per frame: beyond every region
+    if case == "one_series":
+        key = np.zeros(n, np.int32); nk = 1
+        ts = np.sort(ts)
+    if case == "int_metric":
+        x = rng.integers(1, 1000, n)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    got, _ = _compare(orc, ops, key, ts, x, xv, nk, window)
+    names = {name for name, _, _ in _lib.profile_read()}
+    _lib.profile_enable(False)
+    assert "range_stats_kernel<T>+words" in names, names
+    assert ("make_comp_kernel" in names) == (case in ("nonfinite", "long_frames")), names
+    assert np.array_equal(got["perm"], np.arange(n))
+    monkeypatch.setenv("TEMPO_NO_STATS_IN_PLACE", "1")
+    laid, _ = _compare(orc, ops, key, ts, x, xv, nk, window)
+    for name in ("count", "min", "max", "valid", "perm"):
+        assert np.array_equal(got[name], laid[name], equal_nan=got[name].dtype.kind == "f"), name
