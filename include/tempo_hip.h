@@ -594,6 +594,40 @@ size_t tmp_partition_move_workspace_bytes(const tmp_partition_move_args *a);
 int tmp_partition_move(const tmp_partition_move_args *a, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Narrow wire format for the columns of a key shuffle (what Spark's Exchange serialises for
+ * partitionBy(partitionCols), python/tempo/tsdf.py:117-121, :563-572): the key id and up to
+ * TMP_WIRE_MAX_MASKS 0/1 flag columns share one word of key_bytes (1, 2 or 4) bytes --
+ * bit key_bits + m is flag column m -- and every int64 column k travels as its offset from
+ * int_min[k] in int_bytes[k] = 4, 5 or 6 bytes: the low four in wire_lo[k] (uint32), the upper one
+ * or two in wire_hi[k] (uint8 / uint16; not used with 4).  tmp_wire_encode reads key / masks / ints
+ * and writes wire_key / wire_lo / wire_hi; tmp_wire_decode reads those and writes key / masks /
+ * ints: decode(encode(x)) == x bit for bit as long as 0 <= key < 2^key_bits, the flags are 0 / 1
+ * and 0 <= ints[k][i] - int_min[k] < 2^(8 * int_bytes[k]).  Elementwise: rows in any order.  All
+ * columns are device arrays of n entries; one sweep, 16-byte accesses when every column is
+ * 16-byte aligned.
+ */
+#define TMP_WIRE_MAX_MASKS 8
+#define TMP_WIRE_MAX_INTS 8
+typedef struct {
+  int64_t n;
+  int32_t *key;
+  int32_t key_bits;
+  int32_t key_bytes;
+  int32_t n_masks;
+  int32_t n_ints;
+  uint8_t *masks[TMP_WIRE_MAX_MASKS];
+  int64_t *ints[TMP_WIRE_MAX_INTS];
+  int64_t int_min[TMP_WIRE_MAX_INTS];
+  int32_t int_bytes[TMP_WIRE_MAX_INTS];
+  void *wire_key;
+  void *wire_lo[TMP_WIRE_MAX_INTS];
+  void *wire_hi[TMP_WIRE_MAX_INTS];
+} tmp_wire_args;
+
+int tmp_wire_encode(const tmp_wire_args *a, void *stream);
+int tmp_wire_decode(const tmp_wire_args *a, void *stream);
+
 /* Rows per key id over every stride-th row (stride 1 = exact counts): what a balanced owner
  * table is computed from -- Spark has no counterpart, its hash partitioning leaves a hot key's
  * task as long as it is (the skew tsdf.py:164-190 works around).  out_counts: device

@@ -65,6 +65,18 @@ class RangeStatsColsArgs(C.Structure):
                 ("out_stddev", C.POINTER(_vp)), ("out_zscore", C.POINTER(_vp)), ("out_valid", C.POINTER(_vp))]
 
 
+TMP_WIRE_MAX_MASKS = 8
+TMP_WIRE_MAX_INTS = 8
+
+
+class WireArgs(C.Structure):
+    _fields_ = [("n", C.c_int64), ("key", _vp), ("key_bits", C.c_int32), ("key_bytes", C.c_int32),
+                ("n_masks", C.c_int32), ("n_ints", C.c_int32), ("masks", _vp * TMP_WIRE_MAX_MASKS),
+                ("ints", _vp * TMP_WIRE_MAX_INTS), ("int_min", C.c_int64 * TMP_WIRE_MAX_INTS),
+                ("int_bytes", C.c_int32 * TMP_WIRE_MAX_INTS), ("wire_key", _vp),
+                ("wire_lo", _vp * TMP_WIRE_MAX_INTS), ("wire_hi", _vp * TMP_WIRE_MAX_INTS)]
+
+
 class EmaArgs(C.Structure):
     _fields_ = [("n", C.c_int64), ("key", _vp), ("n_keys", C.c_int32), ("ts", _vp),
                 ("ts_is_seconds", C.c_int32), ("seq", _vp), ("seq_valid", _vp), ("x", _vp),
@@ -182,6 +194,8 @@ SYMBOLS = {
     "tmp_hash_partition_workspace_bytes": _WS(PartitionArgs),
     "tmp_hash_partition": _OP(PartitionArgs),
     "tmp_hash_partition_static": (C.c_int, [C.POINTER(PartitionArgs), _vp]),
+    "tmp_wire_encode": (C.c_int, [C.POINTER(WireArgs), _vp]),
+    "tmp_wire_decode": (C.c_int, [C.POINTER(WireArgs), _vp]),
     "tmp_partition_move_workspace_bytes": _WS(PartitionMoveArgs),
     "tmp_partition_move": _OP(PartitionMoveArgs),
     "tmp_key_counts_workspace_bytes": _WS(KeyCountsArgs),

@@ -289,8 +289,18 @@ class WirePlan:
             total += self.int_cols[i][1] if i in self.int_cols else c.element_size()
         return total
 
+    device_kernels = True     # False: the torch expressions on device tensors too (what the tests compare with)
+
+    def _on_device(self, first):
+        """Whether the HIP kernels take the call: device tensors, and no more flag / integer columns than
+        one call holds (host tensors -- the gloo tests -- and wider tables use the torch expressions)."""
+        narrow = sum(1 for _, nb in self.int_cols.values() if nb != 8)
+        return self.device_kernels and first.is_cuda and len(self.mask_cols) <= 8 and narrow <= 8
+
     def encode(self, key, columns):
         """[key, columns...] -> list of wire columns."""
+        if self._on_device(key) and key.dtype == torch.int32:
+            return self._encode_dev(key, columns)
         word = key.to(torch.int32)
         for b, i in enumerate(self.mask_cols):
             word = word | (columns[i].to(torch.int32) << (self.key_bits + b))
@@ -313,8 +323,64 @@ class WirePlan:
                 wire.append(c)
         return wire
 
+    def _encode_dev(self, key, columns):
+        """encode through tmp_wire_encode: one sweep over the table instead of a dozen elementwise ones."""
+        n, dev = key.numel(), key.device
+        word = torch.empty(n, dtype=self.key_dtype, device=dev)
+        masks = [columns[i].contiguous() for i in self.mask_cols]
+        narrow = [i for i in sorted(self.int_cols) if self.int_cols[i][1] != 8]
+        los = {i: torch.empty(n, dtype=torch.int32, device=dev) for i in narrow}
+        his = {i: (None if self.int_cols[i][1] == 4 else
+                   torch.empty(n, dtype=torch.uint8 if self.int_cols[i][1] == 5 else torch.int16, device=dev)) for i in narrow}
+        ops.wire_code(True, key.contiguous(), self.key_bits, word, masks, [columns[i].contiguous() for i in narrow],
+                      [self.int_cols[i][0] for i in narrow], [self.int_cols[i][1] for i in narrow],
+                      [los[i] for i in narrow], [his[i] for i in narrow])
+        wire = [word]
+        for i, c in enumerate(columns):
+            if i in self.mask_cols:
+                continue
+            if i in los:
+                wire.append(los[i])
+                if his[i] is not None:
+                    wire.append(his[i])
+            else:
+                wire.append(c)
+        return wire
+
+    def _decode_dev(self, wire, dtypes):
+        it = iter(wire)
+        word = next(it)
+        n, dev = word.numel(), word.device
+        key = torch.empty(n, dtype=torch.int32, device=dev)
+        cols = [None] * len(dtypes)
+        masks = []
+        for i in self.mask_cols:
+            cols[i] = torch.empty(n, dtype=torch.uint8, device=dev)
+            masks.append(cols[i])
+        narrow, los, his = [], [], []
+        for i, dt in enumerate(dtypes):
+            if i in self.mask_cols:
+                continue
+            if i in self.int_cols and self.int_cols[i][1] != 8:
+                narrow.append(i)
+                los.append(next(it))
+                his.append(None if self.int_cols[i][1] == 4 else next(it))
+                cols[i] = torch.empty(n, dtype=torch.int64, device=dev)
+            else:
+                cols[i] = next(it)
+        ops.wire_code(False, key, self.key_bits, word.contiguous(), masks, [cols[i] for i in narrow],
+                      [self.int_cols[i][0] for i in narrow], [self.int_cols[i][1] for i in narrow],
+                      [t.contiguous() for t in los], [None if t is None else t.contiguous() for t in his])
+        for i in self.mask_cols:
+            cols[i] = cols[i].to(dtypes[i])
+        for i in narrow:
+            cols[i] = cols[i].to(dtypes[i])
+        return key, cols
+
     def decode(self, wire, dtypes):
         """Inverse of encode: (key int32, [columns in their own dtypes])."""
+        if self._on_device(wire[0]):
+            return self._decode_dev(wire, dtypes)
         it = iter(wire)
         word = next(it).to(torch.int32)
         if self.key_dtype == torch.int16:

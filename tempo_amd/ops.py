@@ -680,6 +680,31 @@ def partition_move(key, columns, n_parts, owner_table=None, slices=None, ts=None
         return outs, counts
 
 
+def wire_code(encode, key, key_bits, key_word, masks, ints, int_min, int_bytes, wire_lo, wire_hi):
+    """tmp_wire_encode / tmp_wire_decode over device tensors: key (int32) + masks (uint8 0/1 columns)
+    <-> key_word (uint8 / int16 / int32: key | flags << key_bits), ints[k] (int64) <-> wire_lo[k]
+    (int32, the low four bytes of ints[k] - int_min[k]) and wire_hi[k] (uint8 / int16 or None).
+    encode=True reads the first of each pair and writes the second, False the other way round."""
+    n = key.numel()
+    if len(masks) > _lib.TMP_WIRE_MAX_MASKS or len(ints) > _lib.TMP_WIRE_MAX_INTS:
+        raise NotImplementedError("too many columns for one tmp_wire call")
+    a = _lib.WireArgs()
+    a.n, a.key, a.key_bits, a.key_bytes = n, _p(key), int(key_bits), key_word.element_size()
+    a.n_masks, a.n_ints, a.wire_key = len(masks), len(ints), _p(key_word)
+    for m, t in enumerate(masks):
+        _dev(t, torch.uint8, f"masks[{m}]", n)
+        a.masks[m] = _p(t)
+    for k, t in enumerate(ints):
+        _dev(t, torch.int64, f"ints[{k}]", n)
+        _dev(wire_lo[k], torch.int32, f"wire_lo[{k}]", n)
+        a.ints[k], a.int_min[k], a.int_bytes[k] = _p(t), int(int_min[k]), int(int_bytes[k])
+        a.wire_lo[k] = _p(wire_lo[k])
+        a.wire_hi[k] = None if wire_hi[k] is None else _p(wire_hi[k])
+    _dev(key, torch.int32, "key")
+    fn = lib().tmp_wire_encode if encode else lib().tmp_wire_decode
+    check(fn(C.byref(a), _stream()), "tmp_wire_encode" if encode else "tmp_wire_decode")
+
+
 def key_counts(key, n_keys, stride=1):
     """Rows per key id over every stride-th row: int64[n_keys] on the device."""
     _dev(key, torch.int32, "key")
