@@ -1,7 +1,8 @@
 """The kernels the headline and secondary benches do not reach, each run once or twice on inputs
 that take its path: long frames of withRangeStats (wide_*), withRangeStats over (key, second) cells
 (cell_runs / cell_rows), interpolate (interp_*), the Arrow import's conversion kernel, the write
-layout (event_cols), the match-record gather, and the one-sweep join of ordered tables (sj_*).
+layout (event_cols), the match-record gather, the one-sweep join of ordered tables (sj_*), and the
+narrowing / widening of the columns a key shuffle sends (wire_rows4).
 Prints one JSON line: per kernel the algorithmic bytes one launch moves (every input read once,
 every output written once) -- what profiles/summarize_more.py sets against rocprofv3's counters.
 
@@ -87,6 +88,15 @@ def main():
     algo["sj_merge_kernel"] = h * (12 + 14 + 16 + 3 * 9)            # left key/ts; right key/ts/2 masks; bid, ask; 3 x (value + flag) out
     algo["sj_tile_last_kernel"] = h * 2
     algo["sj_bounds_kernel"] = (h // 512) * 8
+    del j, q
+    # ---- the wire form of the key shuffle: key id + NULL flag in one byte, the time as a 5-byte offset
+    from tempo_amd.dist import WirePlan
+    flag = (torch.rand(n, generator=g, device=dev) >= 0.005).to(torch.uint8)
+    plan = WirePlan(3, [1], {0: (int(ts2[0]), 5)})
+    wire = plan.encode(key, [ts2, flag])
+    back_key, back = plan.decode(wire, [torch.int64, torch.uint8])
+    assert torch.equal(back_key, key) and torch.equal(back[0], ts2) and torch.equal(back[1], flag)
+    algo["wire_rows4_kernel"] = n * (4 + 8 + 1 + 1 + 4 + 1)        # either way: key, ts, flag on one side; byte, low word, high byte on the other
     torch.cuda.synchronize()
     print(json.dumps(dict(rows=n, algorithmic_bytes_per_launch=algo)))
 

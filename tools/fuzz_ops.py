@@ -543,12 +543,66 @@ def case_write_layout(rng):
     return desc
 
 
+def case_wire(rng):
+    """The wire form of a key shuffle: narrowed by the encode kernel to exactly the bytes a numpy
+    restatement gives, widened by the decode kernel back to the table."""
+    from tempo_amd.dist import WirePlan
+    n = max(1, draw_size(rng))
+    key_bits = int(rng.choice([1, 3, 7, 8, 14, 20, 31]))
+    n_masks = int(rng.integers(0, min(8, 32 - key_bits) + 1)) if key_bits < 31 else 0
+    widths = [int(w) for w in rng.choice([4, 5, 6, 8], int(rng.integers(0, 4)))]
+    off = int(rng.integers(0, 4))           # views that start off the 16-byte grid take the row-by-row kernel
+    m = n + off
+    key = rng.integers(0, 1 << key_bits, m).astype(np.int32)
+    masks = [(rng.random(m) > 0.3).astype(np.uint8) for _ in range(n_masks)]
+    ints, mins = [], []
+    for w in widths:
+        lo = int(rng.integers(-(1 << 50), 1 << 50))
+        span = (1 << 62) if w == 8 else (1 << (8 * w))
+        c = lo + rng.integers(0, span, m)
+        c[off], c[m - 1] = lo, lo + span - 1
+        ints.append(c)
+        mins.append(lo)
+    other = rng.normal(0, 1, m)
+    cols = ints + masks + [other]
+    desc = LAST["desc"] = "wire n=%d off=%d key_bits=%d masks=%d ints=%r" % (n, off, key_bits, n_masks, widths)
+    plan = WirePlan(key_bits, list(range(len(ints), len(ints) + n_masks)), {i: (mins[i], widths[i]) for i in range(len(ints))})
+    d_key, d_cols = dev(key)[off:], [dev(c)[off:] for c in cols]
+    wire = plan.encode(d_key, d_cols)
+    word = key[off:].astype(np.int64)
+    for b, f in enumerate(masks):
+        word |= f[off:].astype(np.int64) << (key_bits + b)
+    width = key_bits + n_masks
+    want = [word.astype(np.uint8 if width <= 8 else (np.uint16 if width <= 16 else np.uint32))]
+    for c, lo, w in zip(ints, mins, widths):
+        if w == 8:
+            want.append(c[off:])
+            continue
+        rel = (c[off:] - lo).astype(np.uint64)
+        want.append((rel & 0xffffffff).astype(np.uint32))
+        if w > 4:
+            want.append((rel >> 32).astype(np.uint8 if w == 5 else np.uint16))
+    want.append(other[off:])
+    assert len(wire) == len(want), "%d wire columns, %d expected" % (len(wire), len(want))
+    for i, (g, w) in enumerate(zip(wire, want)):
+        g = g.cpu().numpy()
+        assert g.dtype.itemsize == w.dtype.itemsize, "wire column %d: %d-byte elements, %d expected" % (i, g.dtype.itemsize, w.dtype.itemsize)
+        eq(g.view(w.dtype), w, "wire column %d" % i)
+    back_key, back = plan.decode(wire, [c.dtype for c in d_cols])
+    eq(back_key, key[off:], "key after decode")
+    for i, c in enumerate(cols):
+        eq(back[i], c[off:], "column %d after decode" % i)
+    return desc
+
+
 CASES = [("asof", case_asof, 4), ("range_stats", case_range_stats, 3), ("ema", case_ema, 1), ("lookback", case_lookback, 1),
          ("resample", case_resample, 2), ("grouped_stats", case_grouped, 2), ("interpolate", case_interpolate, 1)]
 # a pool of its own (--extra), so that the case a seed of the first pool names stays the same
 EXTRA_CASES = [("asof_wide", case_asof_wide, 1), ("partition", case_partition, 1), ("write_layout", case_write_layout, 1)]
 # a third pool (--ordered): joins of two tables that are both in order
 ORDERED_CASES = [("asof_ordered", case_asof_ordered, 1)]
+# a fourth pool (--wire): the narrowing / widening kernels of the key shuffle
+WIRE_CASES = [("wire", case_wire, 1)]
 
 
 def main():
@@ -560,11 +614,12 @@ def main():
     ap.add_argument("--extra", action="store_true",
                     help="the second pool: joins of tables wider than one sort word, shuffle routing, write layout")
     ap.add_argument("--ordered", action="store_true", help="the third pool: joins of two tables already in (key, ts) order")
+    ap.add_argument("--wire", action="store_true", help="the fourth pool: wire encoding of the key shuffle's columns")
     ap.add_argument("--only", default="", help="comma-separated operator names")
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "fuzz_ops.log"))
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.log), exist_ok=True)
-    pool = [c for c in (ORDERED_CASES if args.ordered else EXTRA_CASES if args.extra else CASES) if not args.only or c[0] in args.only.split(",")]
+    pool = [c for c in (WIRE_CASES if args.wire else ORDERED_CASES if args.ordered else EXTRA_CASES if args.extra else CASES) if not args.only or c[0] in args.only.split(",")]
     weights = np.array([c[2] for c in pool], dtype=np.float64)
     weights /= weights.sum()
     t_end = time.time() + args.seconds
