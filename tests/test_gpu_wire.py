@@ -99,3 +99,21 @@ def test_wire_call_rejects_what_it_cannot_hold():
         ops.wire_code(True, key, 6, word, [], ints, [0], [7], lo, [None])
     with pytest.raises(ValueError, match="upper part missing"):
         ops.wire_code(True, key, 6, word, [], ints, [0], [5], lo, [None])
+
+
+def test_tables_wider_than_one_call_take_the_torch_expressions():
+    """More than eight flag columns or eight narrowed integer columns: the plan falls back to the
+    elementwise form and the table still comes back bit for bit."""
+    n = 3000
+    g = torch.Generator().manual_seed(3)
+    key = torch.randint(0, 50, (n,), generator=g, dtype=torch.int32).cuda()
+    cols = [torch.randint(0, 1 << 20, (n,), generator=g, dtype=torch.int64).cuda() for _ in range(9)]
+    cols += [torch.randint(0, 2, (n,), generator=g, dtype=torch.uint8).cuda() for _ in range(10)]
+    plan = tdist.plan_wire(key, cols, 50)
+    assert len(plan.mask_cols) == 10 and len(plan.int_cols) == 9
+    assert not plan._on_device(key)
+    wire = plan.encode(key, cols)
+    back_key, back = plan.decode(wire, [c.dtype for c in cols])
+    assert torch.equal(back_key, key)
+    for a, b in zip(back, cols):
+        assert a.dtype == b.dtype and torch.equal(a, b)
