@@ -234,60 +234,71 @@ def main():
         _lib.profile_enable(True)
 
     def step():
-        q = tq
-        t = tk
-        if dist is not None:
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+        def join(q):
+            # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
+            # the left side and the three joined right columns, written by the merge itself
+            _lib.profile_tag(1)
+            marks[0].record()
+            j = ops.asof_join_table(
+                q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
+                [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
+                skip_nulls=True, ts_partition_val=10, fraction=0.1)
+            n1 = (q["ts_l"].numel(), q["ts_r"].numel())
+            log("join enqueued on %d + %d rows" % n1)
+            del j
+            marks[1].record()
+            return n1
+
+        def stats(t):
+            _lib.profile_tag(2)
+            marks[2].record()
+            out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
+            n2 = t["ts"].numel()
+            log("range stats enqueued on %d rows" % n2)
+            del out
+            marks[3].record()
+            return n2
+
+        if dist is None:
+            n1 = join(tq)
+            n2 = stats(tk)
+        else:
             # Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  Owners
             # come from sampled row counts, so that neither the Zipf head of the join keys nor the
             # short symbol list of the tick table leaves one GPU with far more rows than the rest;
             # a join key too hot for one GPU is cut into time slices at bracket boundaries of the
             # skew join (the quotes then carry their bracket tails across slice boundaries).  All
-            # three exchanges are issued up front; the tick table's transfers overlap the join.
+            # three exchanges are issued up front, the smallest first: the rank waits for the tick
+            # table alone (14 of the 33 GB it sends), and the two tables of the join travel while the
+            # statistics are worked out.
             _lib.profile_tag(0)
+            own_ticks = balanced_owners(tk["key"], TICK_KEYS)
             own_join = balanced_owners([tq["key_l"], tq["key_r"]], ASOF_KEYS,
                                        skew=dict(ts_partition_val=10, fraction=0.1),
                                        ts=[tq["ts_l"], tq["ts_r"]])
-            own_ticks = balanced_owners(tk["key"], TICK_KEYS)
             log("owner plans ready (join keys sliced: %s)" % (own_join.slices is not None))
             # the columns travel narrowed: key + NULL flags in one or two bytes, timestamps as 5-byte
             # offsets from the global minimum (dist.WirePlan)
             c_trades = [tq["ts_l"], tq["trade_pr"]]
             c_quotes = [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]]
             c_ticks = [tk["ts"], tk["x"], tk["x_valid"]]
+            p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
+                                           wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
             p_trades = shuffle_by_key_start(tq["key_l"], c_trades, owners=own_join, ts=tq["ts_l"],
                                             wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS))
             p_quotes = shuffle_by_key_start(tq["key_r"], c_quotes, owners=own_join, ts=tq["ts_r"], halo=True,
                                             wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS))
-            p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
-                                           wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
             exchange_bytes.append(p_trades.bytes_sent + p_quotes.bytes_sent + p_ticks.bytes_sent)
             log("exchanges issued")
+            kk, (tt, xx, xv), _, _ = p_ticks.wait()
+            n2 = stats(dict(key=kk, ts=tt, x=xx, x_valid=xv))
+            del kk, tt, xx, xv
+            _lib.profile_tag(0)
             kl, (tl, pr), _, _ = p_trades.wait()
             kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
-            q = dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
-        _lib.profile_tag(1)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        marks[0].record()
-        # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
-        # the left side and the three joined right columns, written by the merge itself
-        j = ops.asof_join_table(
-            q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
-            [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
-            skip_nulls=True, ts_partition_val=10, fraction=0.1)
-        n1 = (q["ts_l"].numel(), q["ts_r"].numel())
-        log("join enqueued on %d + %d rows" % n1)
-        del j
-        marks[1].record()
-        _lib.profile_tag(2)
-        if dist is not None:
-            kk, (tt, xx, xv), _, _ = p_ticks.wait()
-            t = dict(key=kk, ts=tt, x=xx, x_valid=xv)
-        marks[2].record()
-        out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
-        n2 = t["ts"].numel()
-        log("range stats enqueued on %d rows" % n2)
-        del out
-        marks[3].record()
+            n1 = join(dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av))
         op_marks.append(marks)
         return n1, n2
 
