@@ -233,72 +233,84 @@ def main():
     if profiling:
         _lib.profile_enable(True)
 
+    def join(q, marks=None):
+        # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
+        # the left side and the three joined right columns, written by the merge itself
+        _lib.profile_tag(1)
+        if marks:
+            marks[0].record()
+        j = ops.asof_join_table(
+            q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
+            [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
+            skip_nulls=True, ts_partition_val=10, fraction=0.1)
+        n1 = (q["ts_l"].numel(), q["ts_r"].numel())
+        log("join enqueued on %d + %d rows" % n1)
+        del j
+        if marks:
+            marks[1].record()
+        return n1
+
+    def stats(t, marks=None):
+        _lib.profile_tag(2)
+        if marks:
+            marks[2].record()
+        out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
+        n2 = t["ts"].numel()
+        log("range stats enqueued on %d rows" % n2)
+        del out
+        if marks:
+            marks[3].record()
+        return n2
+
+    def start_exchanges():
+        """Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  Owners come
+        from sampled row counts, so that neither the Zipf head of the join keys nor the short symbol
+        list of the tick table leaves one GPU with far more rows than the rest; a join key too hot
+        for one GPU is cut into time slices at bracket boundaries of the skew join (the quotes then
+        carry their bracket tails across slice boundaries).  All three exchanges are issued up front,
+        the smallest first.  The columns travel narrowed: key + NULL flags in one or two bytes,
+        timestamps as 5-byte offsets from the global minimum (dist.WirePlan)."""
+        _lib.profile_tag(0)
+        own_ticks = balanced_owners(tk["key"], TICK_KEYS)
+        own_join = balanced_owners([tq["key_l"], tq["key_r"]], ASOF_KEYS,
+                                   skew=dict(ts_partition_val=10, fraction=0.1),
+                                   ts=[tq["ts_l"], tq["ts_r"]])
+        log("owner plans ready (join keys sliced: %s)" % (own_join.slices is not None))
+        c_trades = [tq["ts_l"], tq["trade_pr"]]
+        c_quotes = [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]]
+        c_ticks = [tk["ts"], tk["x"], tk["x_valid"]]
+        p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
+                                       wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
+        p_trades = shuffle_by_key_start(tq["key_l"], c_trades, owners=own_join, ts=tq["ts_l"],
+                                        wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS))
+        p_quotes = shuffle_by_key_start(tq["key_r"], c_quotes, owners=own_join, ts=tq["ts_r"], halo=True,
+                                        wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS))
+        log("exchanges issued")
+        return p_ticks, p_trades, p_quotes
+
+    def held_ticks(p_ticks):
+        _lib.profile_tag(0)
+        kk, (tt, xx, xv), _, _ = p_ticks.wait()
+        return dict(key=kk, ts=tt, x=xx, x_valid=xv)
+
+    def held_join_tables(p_trades, p_quotes):
+        _lib.profile_tag(0)
+        kl, (tl, pr), _, _ = p_trades.wait()
+        kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
+        return dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av)
+
     def step():
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-
-        def join(q):
-            # the joined table in (key, ts) order, as Spark's window leaves it: key / ts / trade_pr of
-            # the left side and the three joined right columns, written by the merge itself
-            _lib.profile_tag(1)
-            marks[0].record()
-            j = ops.asof_join_table(
-                q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], ASOF_KEYS, [q["trade_pr"]],
-                [q["ts_r"], q["bid"], q["ask"]], [None, q["bid_valid"], q["ask_valid"]],
-                skip_nulls=True, ts_partition_val=10, fraction=0.1)
-            n1 = (q["ts_l"].numel(), q["ts_r"].numel())
-            log("join enqueued on %d + %d rows" % n1)
-            del j
-            marks[1].record()
-            return n1
-
-        def stats(t):
-            _lib.profile_tag(2)
-            marks[2].record()
-            out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], TICK_KEYS, 600)
-            n2 = t["ts"].numel()
-            log("range stats enqueued on %d rows" % n2)
-            del out
-            marks[3].record()
-            return n2
-
         if dist is None:
-            n1 = join(tq)
-            n2 = stats(tk)
+            n1 = join(tq, marks)
+            n2 = stats(tk, marks)
         else:
-            # Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  Owners
-            # come from sampled row counts, so that neither the Zipf head of the join keys nor the
-            # short symbol list of the tick table leaves one GPU with far more rows than the rest;
-            # a join key too hot for one GPU is cut into time slices at bracket boundaries of the
-            # skew join (the quotes then carry their bracket tails across slice boundaries).  All
-            # three exchanges are issued up front, the smallest first: the rank waits for the tick
-            # table alone (14 of the 33 GB it sends), and the two tables of the join travel while the
-            # statistics are worked out.
-            _lib.profile_tag(0)
-            own_ticks = balanced_owners(tk["key"], TICK_KEYS)
-            own_join = balanced_owners([tq["key_l"], tq["key_r"]], ASOF_KEYS,
-                                       skew=dict(ts_partition_val=10, fraction=0.1),
-                                       ts=[tq["ts_l"], tq["ts_r"]])
-            log("owner plans ready (join keys sliced: %s)" % (own_join.slices is not None))
-            # the columns travel narrowed: key + NULL flags in one or two bytes, timestamps as 5-byte
-            # offsets from the global minimum (dist.WirePlan)
-            c_trades = [tq["ts_l"], tq["trade_pr"]]
-            c_quotes = [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]]
-            c_ticks = [tk["ts"], tk["x"], tk["x_valid"]]
-            p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
-                                           wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
-            p_trades = shuffle_by_key_start(tq["key_l"], c_trades, owners=own_join, ts=tq["ts_l"],
-                                            wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS))
-            p_quotes = shuffle_by_key_start(tq["key_r"], c_quotes, owners=own_join, ts=tq["ts_r"], halo=True,
-                                            wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS))
+            # the rank waits for the tick table alone (14 of the 33 GB it sends); the two tables of
+            # the join travel while the statistics are worked out
+            p_ticks, p_trades, p_quotes = start_exchanges()
             exchange_bytes.append(p_trades.bytes_sent + p_quotes.bytes_sent + p_ticks.bytes_sent)
-            log("exchanges issued")
-            kk, (tt, xx, xv), _, _ = p_ticks.wait()
-            n2 = stats(dict(key=kk, ts=tt, x=xx, x_valid=xv))
-            del kk, tt, xx, xv
-            _lib.profile_tag(0)
-            kl, (tl, pr), _, _ = p_trades.wait()
-            kr, (tr, bid, ask, bv, av), _, _ = p_quotes.wait()
-            n1 = join(dict(key_l=kl, ts_l=tl, trade_pr=pr, key_r=kr, ts_r=tr, bid=bid, ask=ask, bid_valid=bv, ask_valid=av))
+            n2 = stats(held_ticks(p_ticks), marks)
+            n1 = join(held_join_tables(p_trades, p_quotes), marks)
         op_marks.append(marks)
         return n1, n2
 
@@ -324,6 +336,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)  # of the warm-up and the timed steps
     rows_per_rank = [[n1[0], n1[1], n2]]
     rccl_ranks = 1
     if dist:
@@ -399,6 +412,30 @@ def main():
         else:
             roofline = dict(bound="hbm", kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=None, traffic=None)
+
+    # ---- the operators alone on what the ranks hold after one more exchange (not part of `value`):
+    # the step less the shuffle, i.e. what tables that arrive partitioned by key would cost
+    held_ms = None
+    if dist:
+        _lib.profile_enable(False)
+        p_ticks, p_trades, p_quotes = start_exchanges()
+        t_held = held_ticks(p_ticks)
+        q_held = held_join_tables(p_trades, p_quotes)
+        del p_ticks, p_trades, p_quotes
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            join(q_held)
+            stats(t_held)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t1) / 2 * 1e3], dtype=torch.float64, device=dev)
+        all_reduce(t, dist.ReduceOp.MAX)
+        held_ms = round(float(t.item()), 3)
+        del t_held, q_held
 
     # ---- the same withRangeStats on a row-permuted copy of the tick table (not part of `value`):
     # what the operator costs when the feed is not time-ordered -- the full (key, second) sort
@@ -513,7 +550,9 @@ def main():
                 "range_stats_shuffled_ms_per_step": None if shuffled_ms is None else round(shuffled_ms, 3),
                 "asof_sorted_input_ms_per_step": None if sorted_ms is None else round(sorted_ms, 3),
                 "range_stats_sorted_input_ms_per_step": None if stats_sorted_ms is None else round(stats_sorted_ms, 3),
-                "peak_hbm_gib_rank0": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                "peak_hbm_gib_rank0": peak_gib,
+                # N > 1: join + statistics alone on what the ranks hold after an exchange (max over ranks)
+                "operators_on_held_rows_ms_per_step": held_ms,
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
                 "range_stats_device_ms_per_step": round(op_ms.get(2, 0.0) / args.steps, 3),

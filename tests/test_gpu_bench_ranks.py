@@ -37,4 +37,7 @@ def test_bench_four_ranks_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["scaling"] == "weak" and out["steps"] == 2
     assert out["value"] > 0 and out["config"]["rows_per_gpu_per_op"] == 4000000
+    assert out["config"]["operators_on_held_rows_ms_per_step"] > 0   # the step less its shuffle, timed beside it
+    held = out["config"]["rows_held_per_rank"]
+    assert len(held) == 4 and sum(r[0] for r in held) == 4 * 2000000 and sum(r[2] for r in held) == 4 * 4000000
     assert "join keys sliced: True" in p.stderr        # the Zipf head is cut along the time axis at 4 ranks
