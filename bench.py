@@ -262,14 +262,16 @@ def main():
             marks[3].record()
         return n2
 
-    def start_exchanges():
+    def start_exchanges(verify=None):
         """Exchange hashpartitioning(key): bucket on device, one all-to-all per column.  Owners come
         from sampled row counts, so that neither the Zipf head of the join keys nor the short symbol
         list of the tick table leaves one GPU with far more rows than the rest; a join key too hot
         for one GPU is cut into time slices at bracket boundaries of the skew join (the quotes then
         carry their bracket tails across slice boundaries).  All three exchanges are issued up front,
         the smallest first.  The columns travel narrowed: key + NULL flags in one or two bytes,
-        timestamps as 5-byte offsets from the global minimum (dist.WirePlan)."""
+        timestamps as 5-byte offsets from the global minimum (dist.WirePlan).  verify=True: per column,
+        the bytes all ranks sent and received must add up to the same checksum (None: as the
+        environment says, off by default)."""
         _lib.profile_tag(0)
         own_ticks = balanced_owners(tk["key"], TICK_KEYS)
         own_join = balanced_owners([tq["key_l"], tq["key_r"]], ASOF_KEYS,
@@ -280,11 +282,11 @@ def main():
         c_quotes = [tq["ts_r"], tq["bid"], tq["ask"], tq["bid_valid"], tq["ask_valid"]]
         c_ticks = [tk["ts"], tk["x"], tk["x_valid"]]
         p_ticks = shuffle_by_key_start(tk["key"], c_ticks, owners=own_ticks,
-                                       wire=plan_wire(tk["key"], c_ticks, TICK_KEYS))
+                                       wire=plan_wire(tk["key"], c_ticks, TICK_KEYS), verify=verify)
         p_trades = shuffle_by_key_start(tq["key_l"], c_trades, owners=own_join, ts=tq["ts_l"],
-                                        wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS))
+                                        wire=plan_wire(tq["key_l"], c_trades, ASOF_KEYS), verify=verify)
         p_quotes = shuffle_by_key_start(tq["key_r"], c_quotes, owners=own_join, ts=tq["ts_r"], halo=True,
-                                        wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS))
+                                        wire=plan_wire(tq["key_r"], c_quotes, ASOF_KEYS), verify=verify)
         log("exchanges issued")
         return p_ticks, p_trades, p_quotes
 
@@ -418,7 +420,7 @@ def main():
     held_ms = None
     if dist:
         _lib.profile_enable(False)
-        p_ticks, p_trades, p_quotes = start_exchanges()
+        p_ticks, p_trades, p_quotes = start_exchanges(verify=True)  # untimed: with the delivery check
         t_held = held_ticks(p_ticks)
         q_held = held_join_tables(p_trades, p_quotes)
         del p_ticks, p_trades, p_quotes
@@ -553,6 +555,8 @@ def main():
                 "peak_hbm_gib_rank0": peak_gib,
                 # N > 1: join + statistics alone on what the ranks hold after an exchange (max over ranks)
                 "operators_on_held_rows_ms_per_step": held_ms,
+                # N > 1: the exchange ahead of that measurement ran with per-column checksums over all ranks
+                "exchange_delivery_checked": held_ms is not None,
                 "parallelism": "key shard x%d (row-count balanced owners)" % args.gpus,
                 "asof_device_ms_per_step": round(op_ms.get(1, 0.0) / args.steps, 3),
                 "range_stats_device_ms_per_step": round(op_ms.get(2, 0.0) / args.steps, 3),
