@@ -27,7 +27,7 @@ def _is_permutation(perm, n):
     return perm.numel() == n and int(seen.sum()) == n
 
 
-def _check_range_stats(gen, n):
+def _check_range_stats(gen, n, ordered=False):
     """withRangeStats(600 s) on n ticks of the benchmark's stream, 100 symbols: row order, frame counts
     (exact) for every row; sums / means of every row against a prefix-sum restatement (1e-7 at 10^8
     rows, 1e-3 at 10^9: the check's own cancellation over a prefix that long, not the kernel's -- a net
@@ -38,9 +38,15 @@ def _check_range_stats(gen, n):
     torch.cuda.empty_cache()
     n_keys, w = 100, 600
     t = gen.gen_ticks(dev, n, n_keys, 2345)
+    if ordered:   # rows laid out in (key, ts) order: the kernel then reads the table's own columns
+        o = torch.argsort(t["key"], stable=True)   # (the stream is time-ordered: a stable sort by key does it)
+        t = {k: v[o].contiguous() for k, v in t.items()}
+        del o
     out = ops.range_stats(t["key"], t["ts"], t["x"], t["x_valid"], n_keys, w)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()   # the call's workspace
+    if ordered:
+        assert torch.equal(out["perm"], torch.arange(n, dtype=out["perm"].dtype, device=dev))
     assert _is_permutation(out["perm"], n)
     p = out["perm"].long()
     sec = torch.div(t["ts"][p], 1_000_000, rounding_mode="floor")
@@ -133,24 +139,45 @@ def test_range_stats_1b_ticks_window_600(gen):
     _check_range_stats(gen, 1_000_000_000)
 
 
-def test_skew_join_1b_rows(gen):
+def test_range_stats_1b_ticks_in_key_ts_order(gen):
+    """10^9 ticks that arrive in (key, ts) order: nothing is laid out, the rows stay where they are."""
+    _check_range_stats(gen, 1_000_000_000, ordered=True)
+
+
+@pytest.mark.parametrize("ordered", [False, True], ids=["random_order", "key_ts_order"])
+def test_skew_join_1b_rows(gen, ordered):
     """asofJoin(tsPartitionVal=10, fraction=0.1) of 5x10^8 trades and 5x10^8 quotes with Zipf keys:
     the joined right timestamp is exactly the latest quote at or before the trade that the
-    trade's bracket may see; NULL-skipping columns take a quote that is visible and not NULL."""
+    trade's bracket may see; NULL-skipping columns take a quote that is visible and not NULL.
+    ordered: both tables laid out in (key, ts) order first -- the one-sweep join, with the left table
+    taken by reference."""
     from tempo_amd import ops
     dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
     n = 500_000_000
     n_keys = 10_000
     q = gen.gen_trades_quotes(dev, n, n, n_keys, 4567)
+    if ordered:
+        for side, cols in (("l", ["key_l", "ts_l", "trade_pr"]), ("r", ["key_r", "ts_r", "bid", "ask", "bid_valid", "ask_valid"])):
+            o = torch.argsort(q["ts_" + side], stable=True)
+            o = o[torch.argsort(q["key_" + side][o], stable=True)]
+            for c in cols:
+                q[c] = q[c][o].contiguous()
+            del o
     j = ops.asof_join_table(q["key_l"], q["ts_l"], q["key_r"], q["ts_r"], n_keys, [q["trade_pr"]],
                             [q["ts_r"], q["bid"]], [None, q["bid_valid"]], skip_nulls=True,
-                            ts_partition_val=10, fraction=0.1)
+                            ts_partition_val=10, fraction=0.1, left_by_reference=ordered)
     torch.cuda.synchronize()
-    assert _is_permutation(j["perm"], n)
-    p = j["perm"].long()
-    assert torch.equal(j["key"], q["key_l"][p]) and torch.equal(j["ts"], q["ts_l"][p])
-    assert torch.equal(j["left"][0], q["trade_pr"][p])
-    del p
+    torch.cuda.empty_cache()
+    if ordered:
+        assert j["in_place"] and j["perm"] is None
+        assert j["key"].data_ptr() == q["key_l"].data_ptr() and j["left"][0].data_ptr() == q["trade_pr"].data_ptr()
+    else:
+        assert _is_permutation(j["perm"], n)
+        p = j["perm"].long()
+        assert torch.equal(j["key"], q["key_l"][p]) and torch.equal(j["ts"], q["ts_l"][p])
+        assert torch.equal(j["left"][0], q["trade_pr"][p])
+        del p
     lcomp = (j["key"].long() << 40) | (j["ts"] - gen.BASE_US)
     assert bool((lcomp[1:] >= lcomp[:-1]).all())                     # (key, ts) order
     rcomp, rorder = torch.sort((q["key_r"].long() << 40) | (q["ts_r"] - gen.BASE_US))
