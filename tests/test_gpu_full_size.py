@@ -27,7 +27,7 @@ def _is_permutation(perm, n):
     return perm.numel() == n and int(seen.sum()) == n
 
 
-def _check_range_stats(gen, n, ordered=False):
+def _check_range_stats(gen, n, ordered=False, layout="time"):
     """withRangeStats(600 s) on n ticks of the benchmark's stream, 100 symbols: row order, frame counts
     (exact) for every row; sums / means of every row against a prefix-sum restatement (1e-7 at 10^8
     rows, 1e-3 at 10^9: the check's own cancellation over a prefix that long, not the kernel's -- a net
@@ -38,6 +38,14 @@ def _check_range_stats(gen, n, ordered=False):
     torch.cuda.empty_cache()
     n_keys, w = 100, 600
     t = gen.gen_ticks(dev, n, n_keys, 2345)
+    if layout == "runs":   # eight time-ordered runs end to end: what a rank holds after a key shuffle
+        o = torch.arange(n, device=dev).view(-1, 8).t().reshape(-1)
+        t = {k: v[o].contiguous() for k, v in t.items()}
+        del o
+    elif layout == "permuted":   # no order at all: the full (key, second) sort
+        o = torch.randperm(n, device=dev)
+        t = {k: v[o].contiguous() for k, v in t.items()}
+        del o
     if ordered:   # rows laid out in (key, ts) order: the kernel then reads the table's own columns
         o = torch.argsort(t["key"], stable=True)   # (the stream is time-ordered: a stable sort by key does it)
         t = {k: v[o].contiguous() for k, v in t.items()}
@@ -142,6 +150,13 @@ def test_range_stats_1b_ticks_window_600(gen):
 def test_range_stats_1b_ticks_in_key_ts_order(gen):
     """10^9 ticks that arrive in (key, ts) order: nothing is laid out, the rows stay where they are."""
     _check_range_stats(gen, 1_000_000_000, ordered=True)
+
+
+@pytest.mark.parametrize("layout", ["runs", "permuted"])
+def test_range_stats_1b_ticks_other_row_orders(gen, layout):
+    """10^9 ticks as a rank holds them after a key shuffle (eight time-ordered runs end to end: the run
+    merge) and in no order at all (the full sort)."""
+    _check_range_stats(gen, 1_000_000_000, layout=layout)
 
 
 @pytest.mark.parametrize("ordered", [False, True], ids=["random_order", "key_ts_order"])
