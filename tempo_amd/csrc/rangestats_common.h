@@ -121,6 +121,23 @@ __device__ __forceinline__ double fast_rcp(double a) {
   double r = __builtin_amdgcn_rcp(a);
   return __builtin_fma(__builtin_fma(-a, r, 1.0), r, r);
 }
+// sqrt(a) as fast_sqrt gives it, and 1 / sqrt(a) from the same reciprocal square root (two coupled
+// Newton steps on the half-reciprocal: within a few ulps).  a <= 0: both 0.
+__device__ __forceinline__ double sqrt_and_rcp(double a, double *inv) {
+  *inv = 0.0;
+  if (!(a > 0.0)) return 0.0;
+  double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, a);  // residual a - g^2
+  g = __builtin_fma(d, h, g);
+  r = __builtin_fma(-h, g, 0.5);       // once more for the reciprocal, against the corrected root
+  h = __builtin_fma(h, r, h);
+  *inv = h + h;
+  return g;
+}
 __device__ __forceinline__ double fast_sqrt(double a) {
   if (!(a > 0.0)) return 0.0;
   double y = __builtin_amdgcn_rsq(a);
