@@ -113,18 +113,22 @@ __global__ __launch_bounds__(EM_THREADS) void ema_kernel(const uint64_t *comp, c
       }
     }
   }
-  const bool vec = i0 + EM_PER <= t1 && (((uintptr_t)out | (uintptr_t)out_perm) & 15) == 0;
+  // (the ordering step may have left the row ids in out_perm itself: nothing to copy then)
+  const bool ids_in_place = (const void *)perm == (const void *)out_perm;
+  const bool vec = i0 + EM_PER <= t1 && (((uintptr_t)out | (uintptr_t)out_perm | (uintptr_t)perm) & 15) == 0;
   if (vec) {
     *reinterpret_cast<double2 *>(out + i0) = make_double2(acc[0], acc[1]);
     *reinterpret_cast<double2 *>(out + i0 + 2) = make_double2(acc[2], acc[3]);
-    const uint4 pv = *reinterpret_cast<const uint4 *>(perm + i0);
-    *reinterpret_cast<uint4 *>(out_perm + i0) = pv;
+    if (!ids_in_place) {
+      const uint4 pv = *reinterpret_cast<const uint4 *>(perm + i0);
+      *reinterpret_cast<uint4 *>(out_perm + i0) = pv;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < EM_PER; ++r)
       if (i0 + r < t1) {
         out[i0 + r] = acc[r];
-        out_perm[i0 + r] = (int32_t)perm[i0 + r];
+        if (!ids_in_place) out_perm[i0 + r] = (int32_t)perm[i0 + r];
       }
   }
 }
@@ -166,6 +170,9 @@ extern "C" int tmp_ema(const tmp_ema_args *a, void *workspace, size_t workspace_
   EmaPlan p;
   ema_plan(a, ws, &p);
   TMP_REQUIRE(workspace && !ws.overflow(), TMP_EWORKSPACE, "tmp_ema: workspace too small");
+  // the second row-id buffer of the ordering step is the caller's out_perm: when the order ends up there
+  // (a single pass does), the row ids are where they belong and the kernel neither reads nor copies them
+  if (((uintptr_t)a->out_perm & 255) == 0) p.ob.idx[1] = (uint32_t *)a->out_perm;  // aligned like the workspace's own
   hipStream_t st = (hipStream_t)stream;
   OrderSpec s;
   memset(&s, 0, sizeof(s));
