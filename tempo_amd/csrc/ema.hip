@@ -101,15 +101,51 @@ __global__ __launch_bounds__(EM_THREADS) void ema_kernel(const uint64_t *comp, c
     m[r] = len < taps ? len : taps;
     acc[r] = 0.0;
   }
-  for (int d = -(EM_PER - 1); d < taps; ++d) {
-    const int at = e0 - d;
-    const double x = at < total ? xv[at] : 0.0;
+  bool deep = true;  // every one of the thread's rows has `taps` rows of its series behind it
 #pragma unroll
-    for (int r = 0; r < EM_PER; ++r) {
-      const int k = d + r;  // uniform over the block
-      if (k >= 0 && k < taps) {
-        const double t = w[k] * x;
-        if (k < m[r]) acc[r] = acc[r] + t;
+  for (int r = 0; r < EM_PER; ++r) deep = deep && m[r] == taps;
+  if (__all(deep) && taps >= EM_PER) {
+    // the common case, without the per-term test: row r takes w[d + r] * x in step d, the weights
+    // slide through registers (one LDS read of a weight per step instead of one per row)
+    static_assert(EM_PER == 4, "four weights in flight");
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = w[0];  // w[d], w[d + 1], w[d + 2], w[d + 3]; 0 outside [0, taps)
+    // steps d = -3 .. -1: only the rows whose tap index d + r is not negative take part
+    {
+      const double xa = xv[e0 + 3], xb = xv[e0 + 2], xc = xv[e0 + 1];
+      acc[3] = acc[3] + w[0] * xa;                               // d = -3: k = 0 for r = 3
+      acc[2] = acc[2] + w[0] * xb; acc[3] = acc[3] + w[1] * xb;  // d = -2
+      acc[1] = acc[1] + w[0] * xc; acc[2] = acc[2] + w[1] * xc; acc[3] = acc[3] + w[2] * xc;  // d = -1
+      w0 = w[0]; w1 = w[1]; w2 = w[2]; w3 = w[3];
+    }
+    int d = 0;
+    for (; d + EM_PER <= taps; ++d) {  // all four tap indices inside [0, taps)
+      const double x = xv[e0 - d];
+      acc[0] = acc[0] + w0 * x;
+      acc[1] = acc[1] + w1 * x;
+      acc[2] = acc[2] + w2 * x;
+      acc[3] = acc[3] + w3 * x;
+      w0 = w1; w1 = w2; w2 = w3;
+      w3 = d + EM_PER < taps ? w[d + EM_PER] : 0.0;
+    }
+    for (; d < taps; ++d) {  // the last three steps: tap indices run off the end for the later rows
+      const double x = xv[e0 - d];
+#pragma unroll
+      for (int r = 0; r < EM_PER; ++r) {
+        const int k = d + r;  // uniform over the block
+        if (k < taps) acc[r] = acc[r] + w[k] * x;
+      }
+    }
+  } else {
+    for (int d = -(EM_PER - 1); d < taps; ++d) {
+      const int at = e0 - d;
+      const double x = at < total ? xv[at] : 0.0;
+#pragma unroll
+      for (int r = 0; r < EM_PER; ++r) {
+        const int k = d + r;  // uniform over the block
+        if (k >= 0 && k < taps) {
+          const double t = w[k] * x;
+          if (k < m[r]) acc[r] = acc[r] + t;
+        }
       }
     }
   }
