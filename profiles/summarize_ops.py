@@ -21,7 +21,7 @@ PEAK = 8.0e12
 # accelerometer table: int32 key, int64 ts, three fp64 channels; sort words are 8 bytes, row ids 4.
 ALGO = {
     # EMA: sort word + carried metric in, EMA + row id out
-    "ema_kernel": 8 + 8 + 8 + 4,
+    "ema_kernel": 8 + 8 + 8,  # sort word + metric in, EMA out (the row ids are left in out_perm by the ordering step)
     # resample(mean, 3 cols): the 3 metric columns, already in sorted order (outputs are per bucket)
     "bucket_reduce_kernel": 3 * 8,
     # resample(mean) without ordering: key + ts + the 3 metric columns in (outputs are per bucket)
