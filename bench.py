@@ -138,6 +138,8 @@ KERNEL_BYTES_PER_ROW = {
     # ... and its scatter, which builds the words: key 4 + ts 8 + NULL flag 1 + metric 8 in, word 8 +
     # row id 4 + metric 8 out (without a travelling column: 13 in, 12 out)
     "radix_scatter_kernel+words+carried": 41.0,
+    "radix_scatter_kernel+words32+carried": 37.0,   # ... with the words going out as 32-bit ones
+    "range_stats_kernel<T>/words32": 69.0,          # the statistics kernel over such words (4 B less in)
     "radix_scatter_kernel+words": 25.0,
     "range_stats_kernel<T>": 73.0,    # word 8 + metric 8 in; 7 stats x 8 + flags 1 out (the row ids are ordered
                                       # straight into the caller's array by the sort, the kernel does not touch them)

@@ -26,12 +26,17 @@ def short(name):
         parts = [a.strip() for a in args.split(",")]
         npay = parts[2]
         if len(parts) > 6 and parts[6] in ("true", "1"):  # the pass that builds the sort words itself
-            base += "+words"
+            base += "+words32" if len(parts) > 7 and parts[7] in ("true", "1") else "+words"
         return base + ("+carried" if npay.startswith("-") else "+payload" if npay != "0" else "")
     if base == "radix_hist_kernel":
         gen = args.split(",")[-1].strip()
         return base + ("+keys" if gen == "3" else "+words" if gen in ("true", "1", "2") else "")
     if base == "range_stats_kernel":
+        parts = [a.strip() for a in args.split(",")]
+        if len(parts) > 3 and parts[3] in ("true", "1"):   # reads 32-bit sort words
+            return "range_stats_kernel<T>/words32"
+        if len(parts) > 2 and parts[2] in ("true", "1"):   # builds the words from the table's columns
+            return "range_stats_kernel<T>+words"
         return "range_stats_kernel<T>"
     if base == "gather_kernel":
         return "gather_kernel<%s>" % args.replace("unsigned long", "uint64_t")

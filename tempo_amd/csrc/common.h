@@ -167,11 +167,15 @@ struct OrderBuffers {
   int64_t key_hist_n;
   uint32_t key_hist_mask;
   const void *key_hist_of;  // the key column it was taken over
+  // host side, set by the caller: sort words that fit 32 bits may be delivered as 32-bit words where
+  // the ordering step has a form for it (OrderResult::narrow says whether they were)
+  bool narrow_words;
 };
 
 struct OrderResult {
   const uint64_t *comp;  // sorted sort words
   const uint32_t *perm;  // perm[p] = input row at sorted position p
+  bool narrow;           // comp holds the words' low 32 bits, one uint32 per row (their upper halves are zero)
 };
 
 // n_keys > 0 also reserves what the bucketed ordering of a large table needs.

@@ -700,12 +700,14 @@ int scan_u32_inplace(uint32_t *counts, int total, hipStream_t st) {
 // written from the one staged copy (the last pass).  0 = separate row ids.
 // GENW: the sort words are not read but built here from the table's columns (first pass of rows
 // whose digit the histogram took from the key column): no pass writes or re-reads plain words.
-template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int PACK, bool GENW = false>
+// NARROW (with GENW): the words fit 32 bits and go out as uint32, one per row, into kout's memory.
+template <int RS_THREADS, int RS_ITEMS, int NPAY, int RS_BITS, bool FIRST, int PACK, bool GENW = false, bool NARROW = false>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
     const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, int64_t n,
     int shift, uint32_t mask, int nbits, int tiles_per_block, const uint32_t *offsets,
     PayPtrs pp, int id_bits, const int32_t *run_if, GenArgs gen) {
   static_assert(!GENW || (FIRST && PACK == 0 && NPAY <= 0), "words are built in the plain first pass only");
+  static_assert(!NARROW || GENW, "32-bit words leave the pass that builds them, and no other pass reads them");
   // NPAY < 0: -NPAY columns that are already in the order of the rows being moved (read by
   // position, no dependent load: the larger plain tile serves, nothing is requested ahead)
   constexpr bool PAY = NPAY != 0;
@@ -908,7 +910,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(
         uint64_t kk = sbuf[p];
         uint32_t d = (uint32_t)(kk >> shift) & mask;
         gpos[j] = goff[d] + ((uint32_t)p - dstart[d]);
-        kout[gpos[j]] = PACK == 2 ? kk >> id_bits : kk;
+        if (NARROW) reinterpret_cast<uint32_t *>(kout)[gpos[j]] = (uint32_t)kk;
+        else kout[gpos[j]] = PACK == 2 ? kk >> id_bits : kk;
       }
     }
     if (PACK == 2) {  // the row ids, from the same staged copy, as a stream of their own
@@ -1841,6 +1844,7 @@ void order_plan(int64_t n, Workspace &ws, OrderBuffers *b, int64_t n_keys, int c
   b->run_if = nullptr;
   b->carry_cols = 0;
   b->key_hist_n = 0;
+  b->narrow_words = false;
   b->key_hist_mask = 0;
   b->key_hist_of = nullptr;
   for (int c = 0; c < 2 * kMaxPay; ++c) b->carry[c] = nullptr;
@@ -2077,7 +2081,7 @@ static bool genw_ok(const GenArgs *gen, int lo, int pack) {
 // the columns that travel with the rows (NPAY = 0 or -1).
 template <int THREADS, int ITEMS, int NPAY, int BITS>
 static void radix_first_pass_fused(OrderBuffers &b, int64_t n, int cur, int lo, int nbits, hipStream_t st,
-                                   const PayPtrs &pp, const GenArgs &gen) {
+                                   const PayPtrs &pp, const GenArgs &gen, bool narrow = false) {
   SortGeom g = sort_geom(n, THREADS * ITEMS);
   const uint32_t mask = (1u << nbits) - 1;
   // the range scan may have left this very histogram in b.counts (same rows, same tiles, the digit
@@ -2093,10 +2097,15 @@ static void radix_first_pass_fused(OrderBuffers &b, int64_t n, int cur, int lo, 
     TMP_LAUNCH(radix_scan_kernel, dim3(1), dim3(1024), st, b.counts, (1 << BITS) * g.grid, b.run_if);
   }
   {
-    ProfScope ps(NPAY == 0 ? "radix_scatter_kernel+words" : "radix_scatter_kernel+words+carried", st);
-    hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, 0, true>), dim3(g.grid), dim3(THREADS),
-                       0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
-                       g.tiles_per_block, b.counts, pp, 0, b.run_if, gen);
+    ProfScope ps(NPAY == 0 ? "radix_scatter_kernel+words" : (narrow ? "radix_scatter_kernel+words32+carried" : "radix_scatter_kernel+words+carried"), st);
+    if (narrow)
+      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, 0, true, true>), dim3(g.grid), dim3(THREADS),
+                         0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                         g.tiles_per_block, b.counts, pp, 0, b.run_if, gen);
+    else
+      hipLaunchKernelGGL((radix_scatter_kernel<THREADS, ITEMS, NPAY, BITS, true, 0, true>), dim3(g.grid), dim3(THREADS),
+                         0, st, b.comp[cur], b.idx[cur], b.comp[cur ^ 1], b.idx[cur ^ 1], n, lo, mask, nbits,
+                         g.tiles_per_block, b.counts, pp, 0, b.run_if, gen);
   }
 }
 
@@ -2165,6 +2174,7 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
                         uint64_t *const *pay_out, bool *carried, const GenArgs *gen,
                         uint64_t *const *carry_buf = nullptr, int *carry_at = nullptr, int start_cur = 0) {
   int cur = start_cur;
+  bool narrow = false;
   if (carried) *carried = false;
   PayPtrs none;
   memset(&none, 0, sizeof(none));
@@ -2216,9 +2226,11 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
       for (int c = 0; c < n_pay; ++c) { pp.src[c] = pay_src[c]; pp.out[c] = pay_out[c]; }
       if (p == 0 && genw_ok(g, lo, pack)) {
         // the only pass: the row ids are the positions, so the payload is read where the rows are
-        // read (no dependent load), and the words are built on the way
+        // read (no dependent load), and the words are built on the way -- as 32-bit words where the
+        // caller takes them and they fit (nothing else will read them: no stand-by passes are enqueued)
         pp.positional = 1;
-        if (nbits <= 8) radix_first_pass_fused<1024, kFusedItems, -1, 8>(b, n, cur, lo, nbits, st, pp, *g);
+        narrow = b.narrow_words && nbits <= 8 && g->lay.total_bits() <= 32 && !b.run_if && !getenv("TEMPO_NO_NARROW_WORDS");
+        if (nbits <= 8) radix_first_pass_fused<1024, kFusedItems, -1, 8>(b, n, cur, lo, nbits, st, pp, *g, narrow);
         else radix_first_pass_fused<1024, kFusedItems, -1, RS_MAX_BITS>(b, n, cur, lo, nbits, st, pp, *g);
       } else if (n_pay == 1)
         radix_one_pass<1024, 6, 1>(b, n, cur, lo, nbits, st, pp, g, false, pack, id_bits);
@@ -2237,6 +2249,7 @@ static int radix_passes(OrderBuffers &b, int64_t n, int lo_bit, int hi_bit, Orde
   TMP_CHECK_HIP(hipGetLastError());
   res->comp = b.comp[cur];
   res->perm = b.idx[cur];
+  res->narrow = narrow;
   return TMP_OK;
 }
 
@@ -2281,6 +2294,11 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
   if (carried) *carried = false;
   res->comp = b.comp[0];
   res->perm = b.idx[0];
+  res->narrow = false;
+  // 32-bit words are on offer to one route only (a time-ordered feed whose key field takes one pass):
+  // every other route re-reads its words, checks them or has stand-by passes that write 64-bit ones
+  const bool narrow_wanted = b.narrow_words;
+  b.narrow_words = false;
   if (s.n <= 0) return TMP_OK;
   GenArgs gen;
   memset(&gen, 0, sizeof(gen));
@@ -2392,7 +2410,10 @@ int order_build(const OrderSpec &s, const Layout &lay, int sorted, OrderBuffers 
       if (carried) *carried = true;
       return TMP_OK;
     }
-    return radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
+    b.narrow_words = narrow_wanted && sorted == 2;
+    const int rc = radix_passes(b, s.n, lo_bit, hi_bit, res, st, n_pay, pay_src, pay_out, carried, &gen);
+    b.narrow_words = false;
+    return rc;
   }
 
   // ---- bucket map: sampled rows per key -> buckets per key -> first bucket per key -> key per bucket

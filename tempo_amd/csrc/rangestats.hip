@@ -176,7 +176,9 @@ struct RsSrc {
 // here from the table's columns (src) -- nothing is laid out beforehand; out_perm is the identity.
 // What this form cannot finish (frames that leave the region, frames with NaN / inf) it marks as
 // deferred, and the caller runs the ordinary form over laid-out words.
-template <typename T, int RK_CAP, bool GENK>
+// W32: `comp` holds 32-bit sort words (the ordering step's narrow form); as with GENK, what would need
+// the 64-bit words -- the serial evaluation of a frame with NaN / inf -- is left to a second run.
+template <typename T, int RK_CAP, bool GENK, bool W32>
 __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_kernel(const uint64_t *comp,
                                                                  const uint32_t *perm,
                                                                  const T *xs, int64_t n, Layout lay,
@@ -202,7 +204,10 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   const int64_t re = t0 + RK_ROWS + RK_FWD < n ? t0 + RK_ROWS + RK_FWD : n;
   const int len = (int)(re - rs);
   uint64_t base;
+  static_assert(!(GENK && W32), "words are either built here or read");
+  const uint32_t *comp32 = reinterpret_cast<const uint32_t *>(comp);
   if (GENK) base = plain_word(lay, src.ts[rs], src.key ? (uint32_t)src.key[rs] : 0u, 0u) >> low;
+  else if (W32) base = (uint64_t)comp32[rs] >> low;
   else base = comp[rs] >> low;
   if (tid == 0) { s.pivot_at = RK_CAP; s.nonfinite = 0; s.x[RK_NULL_AT] = MinMax<T>::null_slot(); }
   __syncthreads();
@@ -225,7 +230,8 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   for (int r = 0; r < kPer; ++r) {
     const int e = r * RK_THREADS + tid;
     const uint32_t at = (uint32_t)(e < len ? e : len - 1);  // (block-uniform base + 32-bit offset: one address register)
-    if (!GENK) wd[r] = (comp + rs)[at];
+    if (W32) wd[r] = (uint64_t)(comp32 + rs)[at];
+    else if (!GENK) wd[r] = (comp + rs)[at];
     xv[r] = (xs + rs)[at];
   }
   if (GENK) {
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   RTICK();
   // A frame that leaves the staged region (or a region too wide for 32-bit relative words) is
   // not evaluated here: the row is marked and the wide path completes it.
-  const bool defer = open_left || open_right || krel >= RK_SAT || (GENK && slow);  // (GENK: no laid-out words for the serial path)
+  const bool defer = open_left || open_right || krel >= RK_SAT || ((GENK || W32) && slow);  // (no 64-bit words laid out for the serial path)
   if (__any(defer) && lane == 0 && __atomic_load_n(deferred, __ATOMIC_RELAXED) == 0) atomicOr(deferred, 1);
   if (defer) {
     o.valid[i] = kDeferred;
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
   }
   if (slow) {
     // a non-finite value inside the frame: exact sequential evaluation (Spark's own recurrence)
-    rs_row_serial<T>(comp, xs, rs + a, rs + b, i, o);
+    if constexpr (!GENK && !W32) rs_row_serial<T>(comp, xs, rs + a, rs + b, i, o);
     return;
   }
   const int64_t cnt = dc & 0xffffu;
@@ -709,21 +715,21 @@ static int rs_region_cap(int64_t n, int64_t n_keys, const Layout &lay, uint64_t 
   return 2560;
 }
 
-template <typename T, bool GENK>
+template <typename T, bool GENK, bool W32 = false>
 static void rs_launch(int cap, int grid, hipStream_t st, const OrderResult &res, const uint32_t *perm, const T *xs, int64_t n,
                       const Layout &lay, uint64_t w, const RsOut<T> &o, int32_t *deferred_flag, int n_tiles, const RsSrc &src) {
-  ProfScope ps(GENK ? "range_stats_kernel<T>+words" : "range_stats_kernel<T>", st);
+  ProfScope ps(GENK ? "range_stats_kernel<T>+words" : (W32 ? "range_stats_kernel<T>/words32" : "range_stats_kernel<T>"), st);
   switch (cap) {
     case 1536:
-      hipLaunchKernelGGL((range_stats_kernel<T, 1536, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+      hipLaunchKernelGGL((range_stats_kernel<T, 1536, GENK, W32>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
                          w, o, deferred_flag, n_tiles, src);
       break;
     case 2048:
-      hipLaunchKernelGGL((range_stats_kernel<T, 2048, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+      hipLaunchKernelGGL((range_stats_kernel<T, 2048, GENK, W32>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
                          w, o, deferred_flag, n_tiles, src);
       break;
     default:
-      hipLaunchKernelGGL((range_stats_kernel<T, 2560, GENK>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
+      hipLaunchKernelGGL((range_stats_kernel<T, 2560, GENK, W32>), dim3(grid), dim3(RK_THREADS), 0, st, res.comp, perm, xs, n, lay,
                          w, o, deferred_flag, n_tiles, src);
   }
 }
@@ -747,6 +753,7 @@ static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_k
   for (;;) {
     TMP_CHECK_HIP(hipMemsetAsync(deferred_flag, 0, sizeof(int32_t), st));
     if (src) rs_launch<T, true>(cap, grid, st, res, perm, xs, n, lay, w, o, deferred_flag, n_tiles, *src);
+    else if (res.narrow) rs_launch<T, false, true>(cap, grid, st, res, perm, xs, n, lay, w, o, deferred_flag, n_tiles, none);
     else rs_launch<T, false>(cap, grid, st, res, perm, xs, n, lay, w, o, deferred_flag, n_tiles, none);
     TMP_CHECK_HIP(hipGetLastError());
     int32_t deferred = 0;
@@ -756,7 +763,7 @@ static int rs_column(const OrderResult &res, const T *xs, int64_t n, int64_t n_k
     if (cap == RK_CAP_MAX || getenv("TEMPO_RK_CAP")) break;
     cap = RK_CAP_MAX;
   }
-  if (src) return kRsNeedWords;
+  if (src || res.narrow) return kRsNeedWords;
   if (!have_wide) {
     set_error("tmp_range_stats: some frames are longer than the on-chip region; call again with a workspace of "
               "tmp_range_stats_wide_workspace_bytes() bytes");
@@ -790,7 +797,7 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   if (sorted_mode(r) == 1 && a->n > 0 && !getenv("TEMPO_NO_STATS_IN_PLACE")) {
     RsSrc src;
     src.key = a->key; src.ts = a->ts; src.valid = a->x_valid;
-    res.comp = nullptr; res.perm = nullptr;
+    res.comp = nullptr; res.perm = nullptr; res.narrow = false;
     const int rc = rs_column<T>(res, (const T *)a->x, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred,
                                 have_wide, p.wide, st, &src);
     if (rc != kRsNeedWords) return rc;
@@ -800,8 +807,16 @@ static int rs_run(const tmp_range_stats_args *a, RsPlan &p, bool have_wide, hipS
   bool carried = false;
   const uint64_t *pay_src[1] = {(const uint64_t *)a->x};
   uint64_t *pay_out[1] = {p.xs};
+  // sort words that fit 32 bits may come as such (half the bytes of that stream, written and read
+  // once each); if some row then needs the 64-bit words after all, the rows are laid out once more
+  p.ob.narrow_words = true;
   TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
   const T *xs = carried ? (const T *)p.xs : (const T *)a->x;
+  int rc = rs_column<T>(res, xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
+  if (rc != kRsNeedWords) return rc;
+  p.ob.narrow_words = false;
+  TMP_TRY(order_build(s, lay, sorted_mode(r), p.ob, &res, st, 1, pay_src, pay_out, &carried));
+  xs = carried ? (const T *)p.xs : (const T *)a->x;
   return rs_column<T>(res, xs, a->n, a->n_keys, lay, (uint64_t)a->range_back_secs, o, p.deferred, have_wide, p.wide, st);
 }
 

@@ -244,6 +244,8 @@ __device__ __forceinline__ void piece_merge(double n_p, double s_p, double q_p, 
   N = nn;
 }
 
+constexpr int64_t kWideDirectRows = 256;  // frames up to this long may be re-added row by row (see wide_rows_kernel)
+
 template <typename T>
 __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, const T *xs, int64_t n,
                                                         Layout lay, uint64_t w, RsOut<T> o, RsWidePlan p) {
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     const int64_t cA = A / WK_CHUNK, cB = B / WK_CHUNK;
     const bool a_first = (A % WK_CHUNK) == 0;
     double N = 0.0, ref = 0.0, rmean = 0.0, M2 = 0.0, dsum = 0.0;
+    double qmag = 0.0;  // size of the prefix values of sum((x - pivot)^2) that the frame's M2 was taken from
     uint64_t cnt = 0, nonfin = 0, isum = 0;
     T mn = W::ident_min(), mx = W::ident_max();
     // everything of chunk c up to and including row r, minus everything before row `from`
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
       nonfin = (c1 >> 16) - (c0 >> 16);
       const double s = p.ps[B] - (a_first ? 0.0 : p.ps[A - 1]);
       const double q = p.pq[B] - (a_first ? 0.0 : p.pq[A - 1]);
+      qmag += p.pq[B];
       if (W::kInt) isum = p.pi[B] - (a_first ? 0ull : p.pi[A - 1]);
       piece_merge((double)(cnt - nonfin), s, q, p.pivot[cA / WK_SUPER], N, ref, rmean, M2, dsum);
       if (!nonfin)
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
         const uint64_t hv = (tc & 0xffffffffull) - (c0 & 0xffffu), hn = (tc >> 32) - (c0 >> 16);
         cnt += hv; nonfin += hn;
         if (W::kInt) isum += p.tot_i[cA] - (a_first ? 0ull : p.pi[A - 1]);
+        qmag += p.tot_q[cA];
         piece_merge((double)(hv - hn), p.tot_s[cA] - (a_first ? 0.0 : p.ps[A - 1]),
                     p.tot_q[cA] - (a_first ? 0.0 : p.pq[A - 1]), p.pivot[cA / WK_SUPER], N, ref, rmean, M2, dsum);
         mn = W::mn(mn, W::val(p.smn[A]));
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
           const uint64_t pv = pc & 0xffffffffull, pn = pc >> 32;
           cnt += pv; nonfin += pn;
           if (W::kInt) isum += p.exc_i[hi] + p.tot_i[hi] - p.exc_i[lo];
+          qmag += p.exc_q[hi] + p.tot_q[hi];
           piece_merge((double)(pv - pn), p.exc_s[hi] + p.tot_s[hi] - p.exc_s[lo],
                       p.exc_q[hi] + p.tot_q[hi] - p.exc_q[lo], p.pivot[s], N, ref, rmean, M2, dsum);
         }
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
         const uint64_t tv = c1 & 0xffffu, tn = c1 >> 16;
         cnt += tv; nonfin += tn;
         if (W::kInt) isum += p.pi[B];
+        qmag += p.pq[B];
         piece_merge((double)(tv - tn), p.ps[B], p.pq[B], p.pivot[cB / WK_SUPER], N, ref, rmean, M2, dsum);
         mn = W::mn(mn, W::val(p.pmn[B]));
         mx = W::mx(mx, W::val(p.pmx[B]));
@@ -323,6 +330,21 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     else sum = (T)dsum;
     const bool x_ok = ((wi >> o.vbit) & 1ull) != 0;
     const bool same = cnt > 1 && mn == mx;  // all values identical: Spark's m2 is exactly 0
+    // The prefix differences carry an absolute error of a few ulps of the prefixes themselves.  A short
+    // frame whose spread is tiny against them (two nearly equal values of a sparse series, say) is
+    // added up again directly, around its own mean; longer ones keep what the prefixes give.
+    if (cnt > 1 && !same && M2 < 1e-5 * qmag && B - A < kWideDirectRows) {
+      const double mean = ref + rmean;
+      double acc = 0.0, lin = 0.0;
+      for (int64_t j = A; j <= B; ++j)
+        if ((comp[j] >> o.vbit) & 1ull) {
+          const double dv = (double)xs[j] - mean;
+          acc += dv * dv;
+          lin += dv;
+        }
+      M2 = acc - lin * lin / N;
+      if (M2 < 0.0) M2 = 0.0;
+    }
     const double sd = cnt > 1 ? (same ? 0.0 : sqrt(M2 / (N - 1.0))) : 0.0;
     rs_store<T>(o, i, (int64_t)cnt, cnt ? ref + rmean : 0.0, mn, mx, sum, cnt > 1, sd, x_ok, x_ok ? (double)xs[i] : 0.0);
   }
