@@ -410,7 +410,10 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
       uint64_t d = kInt ? __shfl_up(ii, off, 64) : 0ull;
       if (lane >= off) { is += a; iq += b; ic += c; ii += d; }
     }
-    double rs_ = is - ts_, rq = iq - tq;  // exclusive over lanes
+    // exclusive over lanes: the lane below's inclusive value, not "inclusive - own" -- a lane whose own
+    // sub-blocks hold far larger values than everything before them would round the small prefix away
+    double rs_ = __shfl_up(is, 1, 64), rq = __shfl_up(iq, 1, 64);
+    if (lane == 0) { rs_ = 0.0; rq = 0.0; }
     uint32_t rc = ic - tc;
     uint64_t ri = ii - ti;
 #pragma unroll
@@ -637,7 +640,9 @@ __global__ __launch_bounds__(RK_THREADS, RK_WAVES_PER_SIMD) void range_stats_ker
     // The prefix difference carries an absolute error of a few ulps of the running total.
     // When the frame's spread is tiny against that total, redo it as a corrected two-pass
     // sum around the frame mean (rare: near-constant frames inside a varying region).
-    if (!same && m2 < 1e-5 * (s.bq[sb] + sq)) {
+    // (the running total up to and including the frame's last sub-block: where the frame ends in the
+    // first half of that sub-block its part was taken as whole - second half, at the size of the whole)
+    if (!same && m2 < 1e-5 * (s.bq[sb + 1] + sq)) {
       double acc = 0.0, lin = 0.0;
       for (int e = a; e <= b; ++e) {
         if (s.ck[e] & 1u) {

@@ -32,14 +32,18 @@ constexpr int64_t kCellKeys = 4096;
 constexpr int64_t kCellMinRows = 1ll << 22;
 
 // Combination of cells: what a run of seconds of one key holds.
+// The mean is kept in two parts, mean + lo: `mean` is a value of the first cell that went in (never
+// changed by a merge), `lo` the small remainder.  Two runs' means then differ by (difference of two
+// nearby doubles, exact) + (difference of two small numbers): the squared difference that enters M2
+// is not limited by the rounding of a mean at the level of the values themselves.
 struct RunAgg {
   uint32_t n;
-  double sum, mean, m2;
+  double sum, mean, lo, m2;
   uint64_t mn, mx;  // coded (code_f64); all ones / zero when n == 0
 };
 __device__ __forceinline__ RunAgg run_empty() {
   RunAgg a;
-  a.n = 0; a.sum = 0.0; a.mean = 0.0; a.m2 = 0.0; a.mn = ~0ull; a.mx = 0ull;
+  a.n = 0; a.sum = 0.0; a.mean = 0.0; a.lo = 0.0; a.m2 = 0.0; a.mn = ~0ull; a.mx = 0ull;
   return a;
 }
 __device__ __forceinline__ RunAgg run_merge(const RunAgg &a, const RunAgg &b) {
@@ -49,8 +53,9 @@ __device__ __forceinline__ RunAgg run_merge(const RunAgg &a, const RunAgg &b) {
   r.n = a.n + b.n;
   r.sum = a.sum + b.sum;
   const double na = (double)a.n, nb = (double)b.n, nn = (double)r.n;
-  const double delta = b.mean - a.mean;
-  r.mean = a.mean + delta * nb / nn;
+  const double delta = (b.mean - a.mean) + (b.lo - a.lo);
+  r.mean = a.mean;
+  r.lo = a.lo + delta * nb / nn;
   r.m2 = a.m2 + b.m2 + delta * delta * na * nb / nn;
   r.mn = a.mn < b.mn ? a.mn : b.mn;
   r.mx = a.mx > b.mx ? a.mx : b.mx;
@@ -62,18 +67,21 @@ struct __attribute__((aligned(64))) RunRec {
   double sum, mean, m2;
   uint64_t mn, mx;
   uint32_t n;
-  uint32_t pad_[5];
+  uint32_t pad_[1];
+  double lo;
+  uint32_t pad2_[2];
 };
+static_assert(sizeof(RunRec) == 64, "one combination, one line");
 typedef RunRec *RunTab;
 __device__ __forceinline__ void run_put(RunTab t, int64_t i, const RunAgg &a) {
   RunRec r;
-  r.sum = a.sum; r.mean = a.mean; r.m2 = a.m2; r.mn = a.mn; r.mx = a.mx; r.n = a.n;
-  r.pad_[0] = r.pad_[1] = r.pad_[2] = r.pad_[3] = r.pad_[4] = 0;
+  r.sum = a.sum; r.mean = a.mean; r.m2 = a.m2; r.mn = a.mn; r.mx = a.mx; r.n = a.n; r.lo = a.lo;
+  r.pad_[0] = r.pad2_[0] = r.pad2_[1] = 0;
   t[i] = r;
 }
 __device__ __forceinline__ RunAgg run_get(const RunRec *t, int64_t i) {
   const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(t + i);
-  const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2];
+  const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
   RunAgg a;
   a.sum = __longlong_as_double((long long)q0.x);
   a.mean = __longlong_as_double((long long)q0.y);
@@ -81,6 +89,7 @@ __device__ __forceinline__ RunAgg run_get(const RunRec *t, int64_t i) {
   a.mn = q1.y;
   a.mx = q2.x;
   a.n = (uint32_t)q2.y;
+  a.lo = __longlong_as_double((long long)q3.x);
   return a;
 }
 
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(kBlock) void cell_runs_kernel(StatTab tab, int64_t 
     a.n = tab.cnt[i];
     if (a.n) {
       a.sum = tab.total[i];
-      a.mean = tab.sum[i];  // the mean by now
+      a.mean = tab.sum[i];  // the mean by now (rounded at the level of the values) ...
+      a.lo = tab.lin[i] / (double)a.n;  // ... and what the second sweep found it to be off by
       const double m2 = tab.acc[i] - tab.lin[i] * tab.lin[i] / (double)a.n;
       a.m2 = m2 < 0.0 ? 0.0 : m2;
       a.mn = tab.mn[i];

@@ -164,6 +164,7 @@ struct RsWidePlan {
   double *exc_s, *exc_q;  // per chunk: exclusive prefix of the totals inside its superblock
   uint64_t *exc_c, *exc_i;
   double *pivot;          // per superblock
+  double *cmean, *cm2;    // per chunk: mean of its finite values (less the superblock's pivot) and their squared deviations from it, added up around the mean itself
   uint64_t *tab_mn, *tab_mx;  // sparse tables over chunk minima / maxima, [levels][chunks]
   int64_t chunks;
   int levels;

@@ -71,6 +71,8 @@ void rs_wide_plan(int64_t n, bool is_i64, Workspace &ws, RsWidePlan *p) {
   p->exc_c = ws.take<uint64_t>(nc);
   p->exc_i = ws.take<uint64_t>(nc);
   p->pivot = ws.take<double>((nc + WK_SUPER - 1) / WK_SUPER);
+  p->cmean = ws.take<double>(nc);
+  p->cm2 = ws.take<double>(nc);
   p->tab_mn = ws.take<uint64_t>(nc * (size_t)levels);
   p->tab_mx = ws.take<uint64_t>(nc * (size_t)levels);
 }
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *co
   __shared__ uint64_t lds_u[16];
   __shared__ uint32_t lds_c[16];
   __shared__ T lds_t[16];
+  __shared__ double chunk_mean_s;
   const int64_t c = blockIdx.x;
   const int64_t i = c * WK_CHUNK + threadIdx.x;
   const bool in = i < n;
@@ -176,7 +179,18 @@ __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *co
   }
   // the chunk's last row holds its totals
   const int64_t last = (c + 1) * WK_CHUNK < n ? (c + 1) * WK_CHUNK - 1 : n - 1;
+  // the chunk's own mean, and the squared deviations from it added up around it (no large sums are
+  // subtracted): what a frame whose spread is tiny against the prefixes is put together from
+  const uint32_t n_fin = (pc & 0xffffu) - (pc >> 16);
+  if (i == last) chunk_mean_s = n_fin ? ps / (double)n_fin : 0.0;
+  __syncthreads();
+  const double dev = fin ? d - chunk_mean_s : 0.0;
+  const double dev1 = block_scan<false>(dev, addd, lds_d);
+  const double dev2 = block_scan<false>(dev * dev, addd, lds_d);
   if (i == last) {
+    const double nf = (double)n_fin;
+    p.cmean[c] = n_fin ? chunk_mean_s + dev1 / nf : 0.0;  // as an offset from the superblock's pivot: small, hence finely resolved
+    p.cm2[c] = n_fin ? dev2 - dev1 * dev1 / nf : 0.0;
     p.tot_s[c] = ps;
     p.tot_q[c] = pq;
     p.tot_c[c] = (uint64_t)(pc & 0xffffu) | ((uint64_t)(pc >> 16) << 32);
@@ -202,9 +216,13 @@ __global__ __launch_bounds__(256) void wide_super_kernel(RsWidePlan p, int64_t s
     uint64_t cc = __shfl_up(ic, o, 64), dd = __shfl_up(ii, o, 64);
     if (lane >= o) { is += a; iq += b; ic += cc; ii += dd; }
   }
+  // (exclusive = the lane below's inclusive value; "inclusive - own" would round a small prefix away
+  // where the chunk's own total is far larger)
+  double es = __shfl_up(is, 1, 64), eq = __shfl_up(iq, 1, 64);
+  if (lane == 0) { es = 0.0; eq = 0.0; }
   if (in) {
-    p.exc_s[c] = is - vs;
-    p.exc_q[c] = iq - vq;
+    p.exc_s[c] = es;
+    p.exc_q[c] = eq;
     p.exc_c[c] = ic - vc;
     p.exc_i[c] = ii - vi;
   }
@@ -243,8 +261,6 @@ __device__ __forceinline__ void piece_merge(double n_p, double s_p, double q_p, 
   M2 += m2_p + delta * delta * (N * n_p / nn);
   N = nn;
 }
-
-constexpr int64_t kWideDirectRows = 256;  // frames up to this long may be re-added row by row (see wide_rows_kernel)
 
 template <typename T>
 __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, const T *xs, int64_t n,
@@ -330,18 +346,32 @@ __global__ __launch_bounds__(256) void wide_rows_kernel(const uint64_t *comp, co
     else sum = (T)dsum;
     const bool x_ok = ((wi >> o.vbit) & 1ull) != 0;
     const bool same = cnt > 1 && mn == mx;  // all values identical: Spark's m2 is exactly 0
-    // The prefix differences carry an absolute error of a few ulps of the prefixes themselves.  A short
-    // frame whose spread is tiny against them (two nearly equal values of a sparse series, say) is
-    // added up again directly, around its own mean; longer ones keep what the prefixes give.
-    if (cnt > 1 && !same && M2 < 1e-5 * qmag && B - A < kWideDirectRows) {
-      const double mean = ref + rmean;
+    // The prefix differences carry an absolute error of a few ulps of the prefixes themselves.  A frame
+    // whose spread is tiny against them (two nearly equal values of a sparse series; a metric that sits
+    // on a level far from the superblock's pivot) is added up again around its own mean: the rows of
+    // the chunks it covers in part one by one, the chunks it covers whole from their own deviations.
+    if (cnt > 1 && !same && M2 < 1e-4 * qmag) {
+      // everything as an offset from `ref` (the first piece's pivot): the values less ref and the
+      // pivots less ref are differences of neighbours, formed without rounding; the centre is ref + rmean
       double acc = 0.0, lin = 0.0;
-      for (int64_t j = A; j <= B; ++j)
-        if ((comp[j] >> o.vbit) & 1ull) {
-          const double dv = (double)xs[j] - mean;
-          acc += dv * dv;
-          lin += dv;
+      for (int64_t c = cA; c <= cB; ++c) {
+        const int64_t c0 = c * WK_CHUNK, c1 = c0 + WK_CHUNK - 1 < n - 1 ? c0 + WK_CHUNK - 1 : n - 1;
+        const int64_t lo = A > c0 ? A : c0, hi = B < c1 ? B : c1;
+        if (lo == c0 && hi == c1) {  // a whole chunk: its own mean and deviations, moved to the frame's mean
+          const uint64_t tc = p.tot_c[c];
+          const double nc = (double)((tc & 0xffffffffull) - (tc >> 32));
+          const double dm = ((p.pivot[c / WK_SUPER] - ref) + p.cmean[c]) - rmean;
+          acc += p.cm2[c] + nc * dm * dm;
+          lin += nc * dm;
+        } else {  // part of a chunk (the frame's two ends at most): row by row
+          for (int64_t j = lo; j <= hi; ++j)
+            if ((comp[j] >> o.vbit) & 1ull) {
+              const double dv = ((double)xs[j] - ref) - rmean;
+              acc += dv * dv;
+              lin += dv;
+            }
         }
+      }
       M2 = acc - lin * lin / N;
       if (M2 < 0.0) M2 = 0.0;
     }

@@ -531,3 +531,82 @@ def test_range_stats_time_ordered_feed_takes_narrow_words(orc, ops, monkeypatch,
     assert len(passes) == 1, passes
     for name in got:
         assert np.array_equal(got[name], wide[name], equal_nan=got[name].dtype.kind == "f"), name
+
+
+@pytest.mark.parametrize("window,stretch_rows", [(60, 5000), (3000, 40000)], ids=["region", "wide_path"])
+def test_range_stats_nearly_constant_stretches(ops, window, stretch_rows):
+    """A metric that sits on a level for a while (noise of 1e-7) and then steps by 0.37: the standard
+    deviation of every frame that lies inside one stretch, against the frame's values added up in
+    extended precision (1e-9).  Frames next to a step are the hard ones: the sums they are taken from
+    have the far larger values of the next stretch as neighbours.  (Spark's own recurrence, and with
+    it the oracle, is good to about 1e-7 on such frames: the comparison is with the exact value.)"""
+    rng = np.random.default_rng(5)
+    n, nk = 400_000, 8
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + np.sort(rng.integers(0, 50_000, n)) * 1_000_000      # one row per second and key
+    stretch = np.arange(n) // stretch_rows
+    level = 100 + stretch * 0.37
+    x = level + rng.normal(0, 1e-7, n)
+    out = ops.range_stats(_dev(key), _dev(ts), _dev(x), None, nk, window)
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    p = g["perm"].astype(np.int64)
+    sec = (ts - BASE) // 1_000_000
+    ks, ss, st = key[p], sec[p], stretch[p]
+    comp = ks.astype(np.int64) * (1 << 40) + ss
+    assert (np.diff(comp) >= 0).all()
+    a = np.searchsorted(comp, comp - np.minimum(ss, window), side="left")
+    b = np.searchsorted(comp, comp, side="right")
+    assert np.array_equal(g["count"], b - a)
+    y = x[p].astype(np.longdouble) - level[p].astype(np.longdouble)   # exact: the level is common to the frame
+    c1 = np.concatenate([[0], np.cumsum(y)])
+    c2 = np.concatenate([[0], np.cumsum(y * y)])
+    cnt = (b - a).astype(np.longdouble)
+    m2 = (c2[b] - c2[a]) - (c1[b] - c1[a]) ** 2 / cnt
+    inside = (st[a] == st[b - 1]) & (cnt > 1)
+    assert inside.sum() > n // 4
+    sd = np.sqrt(np.where(inside, m2 / np.maximum(cnt - 1, 1), 1))
+    err = np.where(inside, np.abs(g["stddev"].astype(np.longdouble) - sd) / sd, 0).astype(np.float64)
+    assert err.max() < 1e-9, (float(err.max()), int((err > 1e-9).sum()), np.flatnonzero(err > 1e-9)[:8])
+    mean = level[p] + ((c1[b] - c1[a]) / cnt).astype(np.float64)
+    assert np.abs(g["mean"] - mean)[inside].max() < 1e-9 * 100
+
+
+def test_range_stats_nearly_constant_stretches_over_cells(ops):
+    """The same through the (key, second) cells that a time-ordered feed may be aggregated over when the
+    caller takes the rows in any order: per-second aggregates merged pairwise, the means carried in two
+    parts so that the difference of two cells' means is not rounded at the level of the values."""
+    from tempo_amd import _lib
+    rng = np.random.default_rng(9)
+    n, nk, w = 1 << 22, 8, 60
+    key = rng.integers(0, nk, n).astype(np.int32)
+    ts = BASE + np.sort(rng.integers(0, (n // 400) * 1_000_000, n))     # 50 rows per second and key
+    stretch = np.arange(n) // 400_000
+    level = 100 + stretch * 0.37
+    x = level + rng.normal(0, 1e-7, n)
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    out = ops.range_stats(_dev(key), _dev(ts), _dev(x), None, nk, w, any_order=True)
+    torch.cuda.synchronize()
+    names = {name for name, _, _ in _lib.profile_read()}
+    _lib.profile_enable(False)
+    assert "cell_rows_kernel" in names, names
+    g = {k: v.cpu().numpy() for k, v in out.items()}
+    p = g["perm"].astype(np.int64)
+    sec = (ts - BASE) // 1_000_000
+    order = np.lexsort((sec, key))
+    ks, ss, st = key[order], sec[order], stretch[order]
+    comp = ks.astype(np.int64) * (1 << 40) + ss
+    a = np.searchsorted(comp, comp - np.minimum(ss, w), side="left")
+    b = np.searchsorted(comp, comp, side="right")
+    y = x[order].astype(np.longdouble) - level[order].astype(np.longdouble)
+    c1 = np.concatenate([[0], np.cumsum(y)])
+    c2 = np.concatenate([[0], np.cumsum(y * y)])
+    cnt = (b - a).astype(np.longdouble)
+    m2 = (c2[b] - c2[a]) - (c1[b] - c1[a]) ** 2 / cnt
+    inside = (st[a] == st[b - 1]) & (cnt > 1)
+    sd = np.sqrt(np.where(inside, m2 / np.maximum(cnt - 1, 1), 1)).astype(np.float64)
+    inv = np.empty(n, np.int64)
+    inv[p] = np.arange(n)
+    assert np.array_equal(g["count"][inv[order]], b - a)
+    err = np.where(inside, np.abs(g["stddev"][inv[order]] - sd) / sd, 0)
+    assert inside.sum() > n // 2 and err.max() < 1e-9, float(err.max())
