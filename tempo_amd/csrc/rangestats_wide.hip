@@ -139,6 +139,7 @@ __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *co
   __shared__ uint32_t lds_c[16];
   __shared__ T lds_t[16];
   __shared__ double chunk_mean_s;
+  __shared__ double dev_sq_s[WK_CHUNK / 64];
   const int64_t c = blockIdx.x;
   const int64_t i = c * WK_CHUNK + threadIdx.x;
   const bool in = i < n;
@@ -185,9 +186,18 @@ __global__ __launch_bounds__(WK_CHUNK) void wide_chunk_kernel(const uint64_t *co
   if (i == last) chunk_mean_s = n_fin ? ps / (double)n_fin : 0.0;
   __syncthreads();
   const double dev = fin ? d - chunk_mean_s : 0.0;
-  const double dev1 = block_scan<false>(dev, addd, lds_d);
-  const double dev2 = block_scan<false>(dev * dev, addd, lds_d);
+  // (totals only: one reduction per wave and sixteen partial sums, not two more scans of the block)
+  double dev1 = dev, dev2 = dev * dev;
+  for (int o = 32; o > 0; o >>= 1) {
+    dev1 += __shfl_xor(dev1, o, 64);
+    dev2 += __shfl_xor(dev2, o, 64);
+  }
+  __syncthreads();  // lds_d may still be read by the last scan
+  if ((threadIdx.x & 63) == 0) { lds_d[threadIdx.x >> 6] = dev1; dev_sq_s[threadIdx.x >> 6] = dev2; }
+  __syncthreads();
   if (i == last) {
+    dev1 = 0.0; dev2 = 0.0;
+    for (int wv = 0; wv < WK_CHUNK / 64; ++wv) { dev1 += lds_d[wv]; dev2 += dev_sq_s[wv]; }
     const double nf = (double)n_fin;
     p.cmean[c] = n_fin ? chunk_mean_s + dev1 / nf : 0.0;  // as an offset from the superblock's pivot: small, hence finely resolved
     p.cm2[c] = n_fin ? dev2 - dev1 * dev1 / nf : 0.0;
