@@ -152,7 +152,7 @@ __global__ __launch_bounds__(DH_THREADS) void dense_stats_kernel(const int32_t *
         const double v = is_i ? (double)(int64_t)raw[r][c] : __longlong_as_double((long long)raw[r][c]);
         const size_t at = (size_t)c * tab.cells + g;
         if (SWEEP == 0) {
-          if (tab.nonfinite && !is_i && !__builtin_isfinite(v) &&
+          if (tab.nonfinite && !is_i && !(__builtin_fabs(v) < 1e150) &&  // NaN, infinite, or large enough for squares to overflow
               __atomic_load_n(tab.nonfinite, __ATOMIC_RELAXED) == 0)
             atomicOr(tab.nonfinite, 1);
           const uint64_t code = is_i ? code_i64((int64_t)raw[r][c]) : code_f64(v);

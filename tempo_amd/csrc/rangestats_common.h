@@ -16,7 +16,10 @@ struct Ord<double> {  // Spark ordering: NaN greatest, -0.0 == 0.0
   }
   static __device__ __forceinline__ double min_id() { return __builtin_nan(""); }
   static __device__ __forceinline__ double max_id() { return -__builtin_inf(); }
-  static __device__ __forceinline__ bool finite(double v) { return __builtin_isfinite(v); }
+  // "finite" for the fast paths: neither NaN nor infinite, and small enough that squares of differences
+  // and sums of thousands of them stay finite -- a frame with anything else is evaluated by Spark's own
+  // recurrence value by value, overflow to infinity included
+  static __device__ __forceinline__ bool finite(double v) { return __builtin_fabs(v) < 1e150; }
 };
 template <>
 struct Ord<int64_t> {

@@ -610,3 +610,16 @@ def test_range_stats_nearly_constant_stretches_over_cells(ops):
     assert np.array_equal(g["count"][inv[order]], b - a)
     err = np.where(inside, np.abs(g["stddev"][inv[order]] - sd) / sd, 0)
     assert inside.sum() > n // 2 and err.max() < 1e-9, float(err.max())
+
+
+@pytest.mark.parametrize("window", [30, 5000])
+def test_range_stats_values_whose_squares_overflow(orc, ops, window):
+    """Values of 1e200: Spark's recurrence overflows to an infinite M2 and reports an infinite standard
+    deviation for every frame that holds one; such frames are evaluated by that recurrence here too
+    (the short frames by the region kernel's serial path, the long ones by the wide path's)."""
+    rng = np.random.default_rng(window)
+    n, nk = 60_000, 3
+    key, ts, x, xv = _ticks(rng, n, nk, 1.0, 0.02)
+    x[rng.integers(0, n, 25)] = rng.choice([1e200, -1e200, 3e160], 25)
+    got, ref = _compare(orc, ops, key, ts, x, xv, nk, window)
+    assert np.isinf(ref["stddev"]).any() and np.array_equal(np.isinf(got["stddev"]), np.isinf(ref["stddev"]))
