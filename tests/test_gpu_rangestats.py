@@ -533,8 +533,9 @@ def test_range_stats_time_ordered_feed_takes_narrow_words(orc, ops, monkeypatch,
         assert np.array_equal(got[name], wide[name], equal_nan=got[name].dtype.kind == "f"), name
 
 
+@pytest.mark.parametrize("in_order", [False, True], ids=["time_ordered", "key_ts_ordered"])
 @pytest.mark.parametrize("window,stretch_rows", [(60, 5000), (3000, 40000)], ids=["region", "wide_path"])
-def test_range_stats_nearly_constant_stretches(ops, window, stretch_rows):
+def test_range_stats_nearly_constant_stretches(ops, window, stretch_rows, in_order):
     """A metric that sits on a level for a while (noise of 1e-7) and then steps by 0.37: the standard
     deviation of every frame that lies inside one stretch, against the frame's values added up in
     extended precision (1e-9).  Frames next to a step are the hard ones: the sums they are taken from
@@ -547,6 +548,9 @@ def test_range_stats_nearly_constant_stretches(ops, window, stretch_rows):
     stretch = np.arange(n) // stretch_rows
     level = 100 + stretch * 0.37
     x = level + rng.normal(0, 1e-7, n)
+    if in_order:   # the table laid out in (key, ts) order: the kernel builds its sort words from the columns
+        o = np.lexsort((ts, key))
+        key, ts, x, stretch, level = key[o], ts[o], x[o], stretch[o], level[o]
     out = ops.range_stats(_dev(key), _dev(ts), _dev(x), None, nk, window)
     g = {k: v.cpu().numpy() for k, v in out.items()}
     p = g["perm"].astype(np.int64)
